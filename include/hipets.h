@@ -1,0 +1,169 @@
+/*
+ * hipets.h -- C ABI of libhipets.so, the MI355X (gfx950) PETS planning / rollout engine.
+ *
+ * Drop-in boundary for ONE hot path of facebookresearch/mbrl-lib (v0.2.0):
+ *
+ *   TrajectoryOptimizerAgent.act -> {CEM,iCEM,MPPI}Optimizer.optimize
+ *       -> ModelEnv.evaluate_action_sequences -> GaussianMLP ensemble -> reward/termination
+ *
+ * The reference is pure Python/PyTorch, so "the reference's FFI for this path" is a ctypes
+ * binding; every entry point below names the reference interface it replaces
+ * (file:line relative to the reference root).  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; hipets_last_error() gives the
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - pointers marked DEVICE point into caller-owned HBM (e.g. torch storage); pointers marked
+ *     HOST are read during the call only.  The library retains no caller pointer past a call,
+ *     except hipets_set_model which copies weights into its own packed layout.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it; there is no hidden device synchronisation.
+ *   - one engine per device; an engine is not thread-safe (the reference is single-threaded).
+ */
+#ifndef HIPETS_H
+#define HIPETS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPETS_ABI_VERSION 1
+#define HIPETS_MAX_LAYERS 8
+
+typedef struct hipets_engine hipets_engine;
+
+/* activation module of GaussianMLP (mbrl/models/gaussian_mlp.py:88-96) */
+enum { HIPETS_ACT_RELU = 0, HIPETS_ACT_SILU = 1, HIPETS_ACT_LEAKY_RELU = 2, HIPETS_ACT_TANH = 3, HIPETS_ACT_SIGMOID = 4 };
+/* Ensemble.propagation_method (mbrl/models/gaussian_mlp.py:201-216) */
+enum { HIPETS_PROP_RANDOM_MODEL = 0, HIPETS_PROP_FIXED_MODEL = 1, HIPETS_PROP_EXPECTATION = 2 };
+/* obs_process_fn (mbrl/env/pets_halfcheetah.py:91-113, mbrl/env/pets_cartpole.py:78-101) */
+enum { HIPETS_OBS_NONE = 0, HIPETS_OBS_HALFCHEETAH = 1, HIPETS_OBS_CARTPOLE_PETS = 2 };
+/* reward_fn (mbrl/env/reward_fns.py:10-53); LEARNED = last model output (model_env.py:124-128) */
+enum { HIPETS_REW_LEARNED = 0, HIPETS_REW_CARTPOLE = 1, HIPETS_REW_CARTPOLE_PETS = 2, HIPETS_REW_INVERTED_PENDULUM = 3,
+       HIPETS_REW_HALFCHEETAH = 4, HIPETS_REW_PUSHER = 5 };
+/* termination_fn (mbrl/env/termination_fns.py:12-95) */
+enum { HIPETS_TERM_NONE = 0, HIPETS_TERM_CARTPOLE = 1, HIPETS_TERM_INVERTED_PENDULUM = 2, HIPETS_TERM_HOPPER = 3,
+       HIPETS_TERM_WALKER2D = 4, HIPETS_TERM_ANT = 5, HIPETS_TERM_HUMANOID = 6 };
+/* Normalizer dtype (mbrl/util/math.py:108-111; normalize_double_precision, one_dim_tr_model.py:87-92) */
+enum { HIPETS_NORM_NONE = 0, HIPETS_NORM_F32 = 1, HIPETS_NORM_F64 = 2 };
+/* randomness source of a rollout */
+enum { HIPETS_MODE_EXACT = 0, /* reference semantics, injected perms / eps (parity mode)      */
+       HIPETS_MODE_FAST = 1   /* whole-horizon persistent kernel, in-kernel Philox (fast mode) */ };
+
+/*
+ * Snapshot of what ModelEnv.evaluate_action_sequences reads from the live objects
+ * (OneDTransitionRewardModel mbrl/models/one_dim_tr_model.py:29-116, GaussianMLP
+ * mbrl/models/gaussian_mlp.py:69-127, EnsembleLinearLayer mbrl/models/util.py:31-65).
+ */
+typedef struct {
+    int32_t obs_dim;         /* raw observation width                                             */
+    int32_t act_dim;         /* action width                                                      */
+    int32_t in_dim;          /* model input width = width(obs_process_fn(obs)) + act_dim          */
+    int32_t out_dim;         /* model output width = obs_dim + learned_rewards                    */
+    int32_t hid;             /* hidden width                                                      */
+    int32_t n_layers;        /* number of linear layers = hidden layers + 1 (<= HIPETS_MAX_LAYERS) */
+    int32_t ensemble_size;   /* E: leading dim of every weight tensor                             */
+    int32_t n_members;       /* M: number of ACTIVE members (elite set, gaussian_mlp.py:161-163)  */
+    const int32_t* members;  /* HOST [M] indices into E                                           */
+    int32_t activation;      /* HIPETS_ACT_*                                                      */
+    float leaky_slope;       /* negative slope for LEAKY_RELU                                     */
+    int32_t propagation;     /* HIPETS_PROP_*                                                     */
+    int32_t deterministic;   /* model has no logvar head (gaussian_mlp.py:113-114)                */
+    int32_t obs_process;     /* HIPETS_OBS_*                                                      */
+    int32_t reward_fn;       /* HIPETS_REW_*                                                      */
+    int32_t termination_fn;  /* HIPETS_TERM_*                                                     */
+    int32_t target_is_delta; /* one_dim_tr_model.py:281-286                                       */
+    int32_t learned_rewards;
+    int32_t n_no_delta;
+    const int32_t* no_delta; /* HOST [n_no_delta] observation dims predicted absolutely           */
+    int32_t normalizer;      /* HIPETS_NORM_*                                                     */
+    const double* norm_mean; /* HOST [in_dim] (f32 stats widened exactly; arithmetic stays f32)   */
+    const double* norm_std;  /* HOST [in_dim]                                                     */
+    const float* min_logvar; /* HOST [out_dim] or NULL if deterministic                           */
+    const float* max_logvar; /* HOST [out_dim]                                                    */
+    const void* const* weights; /* HOST array [n_layers] of DEVICE float [E, in_l, out_l]         */
+    const void* const* biases;  /* HOST array [n_layers] of DEVICE float [E, 1, out_l]            */
+} hipets_model_desc;
+
+/* options of one evaluate_action_sequences call */
+typedef struct {
+    int32_t mode;            /* HIPETS_MODE_*                                                     */
+    /* EXACT mode: the reference's random draws, injected                */
+    const int64_t* perms;    /* DEVICE: random_model [H,B] (one torch.randperm(B) per step,       */
+                             /*   gaussian_mlp.py:205); fixed_model [B] (:375); else NULL         */
+    const float* eps;        /* DEVICE [H,B,out_dim] standard normals consumed by torch.normal    */
+                             /*   (model.py:471-473); NULL => predictions are the mean            */
+    /* FAST mode: counter-based RNG                                                               */
+    uint64_t seed;
+    uint64_t stream_id;      /* e.g. plan counter * iterations + iteration                        */
+    const int32_t* member_schedule; /* DEVICE [H, n_workgroups] optional override (testing)       */
+    const float* fast_eps;   /* DEVICE [H,B,out_dim] optional override of the Philox normals      */
+    /* optional debug taps (DEVICE, may be NULL)                                                  */
+    float* trace_next_obs;   /* [H,B,obs_dim]                                                     */
+    float* trace_rewards;    /* [H,B] reward of the step before termination masking               */
+    int32_t rows_per_group;  /* 0 = auto; else force R (row tiles of 16 per workgroup)            */
+} hipets_rollout_opts;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int hipets_abi_version(void);
+const char* hipets_last_error(void);
+int hipets_create(int device, hipets_engine** out);
+void hipets_destroy(hipets_engine* e);
+
+/* Re-snapshot weights / normaliser / elite set (call after ModelTrainer.train,
+ * mbrl/models/model_trainer.py:288-296).  Packs into the MFMA fragment layout. */
+int hipets_set_model(hipets_engine* e, const hipets_model_desc* desc, void* stream);
+
+/* ---- ModelEnv.evaluate_action_sequences (mbrl/models/model_env.py:145-191) ---------------- */
+/* actions DEVICE [pop,H,A] f32; s0 HOST [obs_dim] f32; returns DEVICE [pop] f32.              */
+int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t horizon,
+                   int32_t num_particles, const hipets_rollout_opts* opts, float* returns, void* stream);
+/* geometry the FAST kernel will use for (pop, P): workgroups and rows per group (for member_schedule) */
+int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t rows_per_group,
+                         int32_t* n_workgroups, int32_t* row_tiles);
+
+/* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
+typedef struct {
+    int32_t population_size, horizon, act_dim;
+    int32_t num_iterations;
+    int32_t elite_num;          /* ceil(pop * elite_ratio), trajectory_opt.py:89-91             */
+    double alpha;               /* momentum; (1 - alpha) is formed in double like the Python reference */
+    int32_t return_mean_elites;
+    int32_t clipped_normal;
+    int32_t unbiased_var;       /* 1 = CEM (:137), 0 = iCEM (:479)                               */
+} hipets_cem_params;
+
+/* _sample_population (:110-128).  z DEVICE [pop,H,A] optional injected N(0,1) draws (already
+ * truncated for the truncated-normal branch); NULL => Philox(seed, stream_id).  lower/upper/mu/
+ * dispersion DEVICE [H,A]; population DEVICE [pop,H,A] out.                                    */
+int hipets_cem_sample(hipets_engine* e, const hipets_cem_params* p, const float* mu, const float* dispersion,
+                      const float* lower, const float* upper, const float* z, uint64_t seed, uint64_t stream_id,
+                      float* population, void* stream);
+/* NaN->-1e-10 (:178), topk (:179), elite mean/var refit with momentum (:130-140), best-so-far
+ * (:184-186).  values DEVICE [pop] (modified in place like the reference); mu/dispersion in-out;
+ * best_value DEVICE [1] in-out (init -inf); best_solution DEVICE [H,A] in-out;
+ * elite_idx DEVICE [elite_num] int32 out (optional).                                           */
+int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values, const float* population,
+                     float* mu, float* dispersion, float* best_value, float* best_solution, int32_t* elite_idx,
+                     void* stream);
+
+/* Whole CEMOptimizer.optimize with the engine's rollout as objective, no host round trip
+ * (replaces trajectory_opt.py:142-188 + the closure at :743-748).  x0/lower/upper DEVICE [H,A];
+ * out DEVICE [H,A] = mu if return_mean_elites else best.  FAST mode rollouts. `scratch` may be
+ * NULL (engine-owned workspace).                                                              */
+int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower,
+                    const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
+                    float* out, void* stream);
+
+/* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
+/* When enabled, every rollout-kernel launch is bracketed by hipEvents on `stream`.              */
+int hipets_timing_enable(hipets_engine* e, int32_t on);
+/* Synchronises the recorded events; returns number of launches and their summed duration.       */
+int hipets_timing_read(hipets_engine* e, int64_t* launches, double* total_ms, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPETS_H */

@@ -1,0 +1,158 @@
+// cem.hpp -- population sampling and elite refit kernels for the trajectory optimizers.
+//
+// Replaces the torch op sequences of CEMOptimizer._sample_population / _update_population_params /
+// optimize (mbrl/planning/trajectory_opt.py:110-188) and mbrl.util.math.truncated_normal_
+// (mbrl/util/math.py:69-92, a host-synchronising rejection loop in the reference).
+#pragma once
+#include "common.hpp"
+
+namespace hipets {
+
+struct CemDev {
+    int pop, H, A, D;  // D = H*A
+    int K;             // elite_num
+    float alpha, one_minus_alpha;
+    int return_mean, clipped, unbiased;
+};
+
+// Standard normal truncated to [-2, 2] by rejection: the stationary law of the reference's
+// redraw-until-inside loop (util/math.py:83-91).  Counter = (element, attempt).
+__device__ __forceinline__ float philox_trunc_normal(uint32_t idx_lo, uint32_t idx_hi, uint64_t seed, uint64_t stream) {
+    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+        const Philox4 r = philox4x32_10(idx_lo, idx_hi, attempt, (uint32_t)stream, (uint32_t)seed,
+                                        (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32) ^ 0x5EED5EEDu);
+        float n0, n1, n2, n3;
+        box_muller(r.x, r.y, n0, n1);
+        if (fabsf(n0) <= 2.0f) return n0;
+        if (fabsf(n1) <= 2.0f) return n1;
+        box_muller(r.z, r.w, n2, n3);
+        if (fabsf(n2) <= 2.0f) return n2;
+        if (fabsf(n3) <= 2.0f) return n3;
+    }
+    return 0.0f;  // P(reached) = 0.0455^256
+}
+
+__device__ __forceinline__ float philox_normal(uint32_t idx_lo, uint32_t idx_hi, uint64_t seed, uint64_t stream) {
+    const Philox4 r = philox4x32_10(idx_lo, idx_hi, 0u, (uint32_t)stream, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32) ^ 0x5EED5EEDu);
+    float n0, n1;
+    box_muller(r.x, r.y, n0, n1);
+    return n0;
+}
+
+// trajectory_opt.py:110-128
+__global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, const float* __restrict__ disp,
+                                  const float* __restrict__ lower, const float* __restrict__ upper,
+                                  const float* __restrict__ z_in, unsigned long long seed, unsigned long long stream,
+                                  float* __restrict__ population) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)p.pop * p.D) return;
+    const int d = (int)(i % p.D);
+    const float m = mu[d], v = disp[d], lb = lower[d], ub = upper[d];
+    float x;
+    if (p.clipped) {  // :116-120
+        const float z = z_in ? z_in[i] : philox_normal((uint32_t)i, (uint32_t)(i >> 32), seed, stream);
+        x = m + v * z;
+        x = x > lb ? x : lb;
+        x = x < ub ? x : ub;
+    } else {  // :122-128
+        const float lbd = (m - lb) / 2.0f, ubd = (ub - m) / 2.0f;
+        const float mv = fminf(lbd * lbd, ubd * ubd);
+        const float cv = fminf(mv, v);
+        const float z = z_in ? z_in[i] : philox_trunc_normal((uint32_t)i, (uint32_t)(i >> 32), seed, stream);
+        x = z * sqrtf(cv) + m;
+    }
+    population[i] = x;
+}
+
+// NaN filter + top-k + refit + best-so-far in ONE workgroup (pop <= kMaxPop): values are sorted with
+// a bitonic network in LDS (descending, ties broken by lower index), then each thread owns
+// dimensions d of the [H,A] plan and reduces the K elites in f64.
+constexpr int kRefitThreads = 1024;
+constexpr int kMaxPop = 8192;
+
+__global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* __restrict__ values,
+                                                                 const float* __restrict__ population, float* __restrict__ mu,
+                                                                 float* __restrict__ disp, float* __restrict__ best_value,
+                                                                 float* __restrict__ best_solution, int* __restrict__ elite_idx_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int n2 = 1;
+    while (n2 < p.pop) n2 <<= 1;
+    float* key = reinterpret_cast<float*>(smem);
+    int* idx = reinterpret_cast<int*>(smem + (size_t)n2 * 4);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n2; i += kRefitThreads) {
+        float v = -INFINITY;
+        if (i < p.pop) {
+            v = values[i];
+            if (v != v) { v = -1e-10f; values[i] = v; }  // trajectory_opt.py:178
+        }
+        key[i] = v;
+        idx[i] = i < p.pop ? i : 0x7FFFFFFF;
+    }
+    __syncthreads();
+    // bitonic sort, "a before b" iff (key_a > key_b) or (equal and idx_a < idx_b)
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += kRefitThreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float ka = key[i], kb = key[ixj];
+                    const int ia = idx[i], ib = idx[ixj];
+                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+                    const bool up = (i & k) == 0;  // descending block
+                    if (up ? !a_first : a_first) {
+                        key[i] = kb; key[ixj] = ka;
+                        idx[i] = ib; idx[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (elite_idx_out)
+        for (int k = tid; k < p.K; k += kRefitThreads) elite_idx_out[k] = idx[k];
+
+    // best-so-far (trajectory_opt.py:184-186)
+    const float top = key[0];
+    const bool improved = top > best_value[0];
+    const int top_i = idx[0];
+    __syncthreads();
+
+    for (int d = tid; d < p.D; d += kRefitThreads) {
+        double s = 0.0;
+        for (int k = 0; k < p.K; ++k) s += (double)population[(size_t)idx[k] * p.D + d];
+        const double mean = s / (double)p.K;
+        double ss = 0.0;
+        for (int k = 0; k < p.K; ++k) {
+            const double dv = (double)population[(size_t)idx[k] * p.D + d] - mean;
+            ss += dv * dv;
+        }
+        double var = ss / (double)(p.unbiased ? (p.K - 1) : p.K);
+        const float new_mu = (float)mean;
+        const float new_disp = p.clipped ? (float)sqrt(var) : (float)var;  // :134-137
+        mu[d] = p.alpha * mu[d] + p.one_minus_alpha * new_mu;               // :138
+        disp[d] = p.alpha * disp[d] + p.one_minus_alpha * new_disp;         // :139
+        if (improved) best_solution[d] = population[(size_t)top_i * p.D + d];
+    }
+    if (improved && tid == 0) best_value[0] = top;
+}
+
+__global__ void fill_kernel(float* p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// trajectory_opt.py:103-108: dispersion0 = ones (clipped) or ((ub - lb)^2) / 16; mu0 = x0
+__global__ void cem_init_kernel(const CemDev p, const float* x0, const float* lower, const float* upper, float* mu,
+                                float* disp, float* best_value) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < p.D) {
+        mu[d] = x0[d];
+        const float w = upper[d] - lower[d];
+        disp[d] = p.clipped ? 1.0f : (w * w) / 16.0f;
+    }
+    if (d == 0) best_value[0] = -INFINITY;
+}
+
+}  // namespace hipets

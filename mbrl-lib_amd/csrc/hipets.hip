@@ -1,0 +1,528 @@
+// hipets.hip -- C-ABI implementation (see include/hipets.h).  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hipets.h"
+#include "cem.hpp"
+#include "rollout.hpp"
+
+using namespace hipets;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HCHECK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+constexpr int kMaxR = 4;
+
+}  // namespace
+
+struct hipets_engine {
+    int device = 0;
+    int num_cu = 256;
+    size_t lds_max = 160 * 1024;
+    bool has_model = false;
+    ModelDev md{};
+    int ensemble_size = 0;
+    DevBuf wpack, bpack, layer_meta, norm_mean, norm_std, min_lv, max_lv, no_delta, members;
+    // rollout workspace
+    DevBuf s0, state, totals, term, schedule;
+    // plan workspace
+    DevBuf mu, disp, population, values, best_value, best_solution, lower_tmp;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    bool lds_attr_set[kMaxR + 1] = {false, false, false, false, false};
+};
+
+namespace {
+
+template <int R>
+int launch_rollout_r(hipets_engine* e, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
+    if (!e->lds_attr_set[R]) {
+        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<R>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_max));
+        e->lds_attr_set[R] = true;
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e->timing) {
+        if (!e->event_pool.empty()) {
+            a = e->event_pool.back().first;
+            b = e->event_pool.back().second;
+            e->event_pool.pop_back();
+        } else {
+            HCHECK(hipEventCreate(&a));
+            HCHECK(hipEventCreate(&b));
+        }
+        HCHECK(hipEventRecord(a, st));
+    }
+    hipLaunchKernelGGL(rollout_kernel<R>, dim3(grid), dim3(kThreads), lds, st, e->md, ra);
+    HCHECK(hipGetLastError());
+    if (e->timing) {
+        HCHECK(hipEventRecord(b, st));
+        e->events.emplace_back(a, b);
+    }
+    return 0;
+}
+
+int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
+    switch (R) {
+        case 1: return launch_rollout_r<1>(e, grid, lds, ra, st);
+        case 2: return launch_rollout_r<2>(e, grid, lds, ra, st);
+        case 3: return launch_rollout_r<3>(e, grid, lds, ra, st);
+        case 4: return launch_rollout_r<4>(e, grid, lds, ra, st);
+        default: return fail("unsupported rows_per_group %d (1..%d)", R, kMaxR);
+    }
+}
+
+size_t lds_for(const hipets_engine* e, int R) {
+    const ModelDev& md = e->md;
+    return rollout_smem_bytes(kTile * R, md.ld, md.obs_dim, md.act_dim, md.out_total,
+                              md.propagation == HIPETS_PROP_EXPECTATION);
+}
+
+// cost model for the row-tile count R of a workgroup: (sequential workgroup rounds per CU) x (MFMA units
+// the busiest wave issues per hidden layer).  See DESIGN.md "Choosing R".
+int wave_units(int C, int R) {
+    const int full = C / kWaves, rem = C % kWaves;
+    return full * R + (rem * R + kWaves - 1) / kWaves;
+}
+
+int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced) {
+    if (forced > 0) return forced;
+    const int C = e->md.hidC;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int R = 1; R <= kMaxR; ++R) {
+        if (lds_for(e, R) > e->lds_max) break;
+        const long long groups = (tiles_total_per_slice + R - 1) / R;
+        const long long nwg = groups * slices;
+        const long long rounds = (nwg + e->num_cu - 1) / e->num_cu;
+        const double cost = (double)rounds * wave_units(C, R);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = R;
+        }
+    }
+    return best;
+}
+
+CemDev make_cem(const hipets_cem_params* p) {
+    CemDev c{};
+    c.pop = p->population_size;
+    c.H = p->horizon;
+    c.A = p->act_dim;
+    c.D = p->horizon * p->act_dim;
+    c.K = p->elite_num;
+    c.alpha = (float)p->alpha;
+    c.one_minus_alpha = (float)(1.0 - (double)p->alpha);
+    c.return_mean = p->return_mean_elites;
+    c.clipped = p->clipped_normal;
+    c.unbiased = p->unbiased_var;
+    return c;
+}
+
+int check_cem(const hipets_cem_params* p) {
+    if (!p) return fail("null cem params");
+    if (p->population_size < 1 || p->population_size > kMaxPop)
+        return fail("population_size %d outside [1, %d]", p->population_size, kMaxPop);
+    if (p->elite_num < 1 || p->elite_num > p->population_size) return fail("elite_num %d invalid", p->elite_num);
+    if (p->unbiased_var && !p->clipped_normal && p->elite_num < 2) {
+        // torch.var of one sample is NaN in the reference too; allowed, just flagged by NaN results
+    }
+    if (p->horizon < 1 || p->act_dim < 1) return fail("bad horizon/act_dim");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipets_abi_version(void) { return HIPETS_ABI_VERSION; }
+
+const char* hipets_last_error(void) { return g_err.c_str(); }
+
+int hipets_create(int device, hipets_engine** out) {
+    if (!out) return fail("null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0)
+        return fail("no HIP device visible (%s) -- libhipets has no CPU fallback", hipGetErrorString(err));
+    if (device < 0 || device >= n) return fail("device %d out of range (%d visible)", device, n);
+    HCHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HCHECK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail("device %d is %s; libhipets is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    auto* e = new hipets_engine();
+    e->device = device;
+    e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->lds_max = prop.sharedMemPerBlockOptin > 0 ? (size_t)prop.sharedMemPerBlockOptin : (size_t)prop.sharedMemPerBlock;
+    if (e->lds_max > 160 * 1024) e->lds_max = 160 * 1024;
+    *out = e;
+    return 0;
+}
+
+void hipets_destroy(hipets_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
+                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->mu, &e->disp, &e->population, &e->values,
+                      &e->best_value, &e->best_solution, &e->lower_tmp})
+        b->release();
+    for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete e;
+}
+
+int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream) {
+    if (!e || !d) return fail("null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    if (d->n_layers < 2 || d->n_layers > HIPETS_MAX_LAYERS) return fail("n_layers %d outside [2, %d]", d->n_layers, HIPETS_MAX_LAYERS);
+    if (d->n_members < 1 || d->n_members > d->ensemble_size) return fail("n_members %d invalid for ensemble_size %d", d->n_members, d->ensemble_size);
+    if (d->obs_dim < 1 || d->act_dim < 1 || d->in_dim < d->act_dim + 1 || d->hid < 1) return fail("bad dimensions");
+    if (d->out_dim != d->obs_dim + (d->learned_rewards ? 1 : 0)) return fail("out_dim %d != obs_dim %d + learned_rewards %d", d->out_dim, d->obs_dim, d->learned_rewards);
+    const int obs_in = d->in_dim - d->act_dim;
+    const int expect_in = d->obs_process == HIPETS_OBS_CARTPOLE_PETS ? d->obs_dim + 1 : d->obs_dim;
+    if (obs_in != expect_in) return fail("in_dim %d inconsistent with obs_dim %d / obs_process %d / act_dim %d", d->in_dim, d->obs_dim, d->obs_process, d->act_dim);
+    if (d->reward_fn == HIPETS_REW_LEARNED && !d->learned_rewards) return fail("reward_fn LEARNED needs learned_rewards");
+    if (d->reward_fn == HIPETS_REW_HALFCHEETAH && d->obs_dim < 3) return fail("halfcheetah reward needs obs_dim >= 3");
+    if (d->reward_fn == HIPETS_REW_PUSHER && d->obs_dim < 20) return fail("pusher reward needs obs_dim >= 20");
+    if ((d->reward_fn == HIPETS_REW_CARTPOLE || d->termination_fn == HIPETS_TERM_CARTPOLE) && d->obs_dim < 3) return fail("cartpole fns need obs_dim >= 3");
+    if ((d->obs_process == HIPETS_OBS_HALFCHEETAH) && d->obs_dim < 3) return fail("halfcheetah obs_process needs obs_dim >= 3");
+    if (d->obs_dim < 2 && (d->termination_fn != HIPETS_TERM_NONE || d->reward_fn == HIPETS_REW_CARTPOLE_PETS)) return fail("termination/reward fn needs obs_dim >= 2");
+    if (!d->deterministic && (!d->min_logvar || !d->max_logvar)) return fail("logvar bounds missing");
+    if (d->normalizer != HIPETS_NORM_NONE && (!d->norm_mean || !d->norm_std)) return fail("normalizer stats missing");
+    for (int i = 0; i < d->n_members; ++i)
+        if (d->members[i] < 0 || d->members[i] >= d->ensemble_size) return fail("member index %d out of range", d->members[i]);
+
+    ModelDev md{};
+    md.obs_dim = d->obs_dim; md.act_dim = d->act_dim; md.in_dim = d->in_dim; md.out_dim = d->out_dim;
+    md.out_total = d->deterministic ? d->out_dim : 2 * d->out_dim;
+    md.hid = d->hid; md.n_layers = d->n_layers; md.M = d->n_members; md.obs_in = obs_in;
+    md.activation = d->activation; md.slope = d->leaky_slope; md.propagation = d->propagation;
+    md.deterministic = d->deterministic; md.obs_process = d->obs_process; md.reward_fn = d->reward_fn;
+    md.term_fn = d->termination_fn; md.target_is_delta = d->target_is_delta; md.learned_rewards = d->learned_rewards;
+    md.normalizer = d->normalizer;
+    auto up16 = [](int x) { return (x + 15) / 16 * 16; };
+    long long woff = 0;
+    int boff = 0, maxK = 0;
+    std::vector<int> Ks(d->n_layers), Ns(d->n_layers);
+    std::vector<LayerMeta> lms(d->n_layers);
+    for (int l = 0; l < d->n_layers; ++l) {
+        Ks[l] = l == 0 ? d->in_dim : d->hid;
+        Ns[l] = l == d->n_layers - 1 ? md.out_total : d->hid;
+        lms[l].Kp = up16(Ks[l]);
+        lms[l].Np = up16(Ns[l]);
+        lms[l].woff = woff;
+        lms[l].boff = boff;
+        lms[l].pad_ = 0;
+        woff += (long long)lms[l].Kp * lms[l].Np;
+        boff += lms[l].Np;
+        maxK = std::max(maxK, std::max(lms[l].Kp, lms[l].Np));
+    }
+    md.Kp0 = lms[0].Kp;
+    md.hidC = up16(d->hid) / kTile;
+    md.wmember = woff;
+    md.bmember = boff;
+    // row stride: >= widest activation, == 8 (mod 64) floats => conflict-free ds_read_b128 A fragments
+    int ld = maxK;
+    while (ld % 64 != 8) ld += 4;
+    md.ld = ld;
+    if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.out_total, md.propagation == HIPETS_PROP_EXPECTATION) > e->lds_max)
+        return fail("model too wide for LDS (ld=%d)", md.ld);
+
+    if (e->wpack.ensure((size_t)md.wmember * md.M * 4)) return 1;
+    if (e->bpack.ensure((size_t)md.bmember * md.M * 4)) return 1;
+    if (e->members.ensure((size_t)md.M * 4)) return 1;
+    HCHECK(hipMemcpyAsync(e->members.p, d->members, (size_t)md.M * 4, hipMemcpyHostToDevice, st));
+    if (e->layer_meta.ensure(sizeof(LayerMeta) * d->n_layers)) return 1;
+    HCHECK(hipMemcpyAsync(e->layer_meta.p, lms.data(), sizeof(LayerMeta) * d->n_layers, hipMemcpyHostToDevice, st));
+    for (int l = 0; l < d->n_layers; ++l) {
+        const long long n = (long long)lms[l].Kp * lms[l].Np * md.M;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e->wpack.as<float>(),
+                           reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp,
+                           lms[l].Np, md.wmember, lms[l].woff);
+        HCHECK(hipGetLastError());
+        const int nb = md.M * lms[l].Np;
+        hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
+                           reinterpret_cast<const float*>(d->biases[l]), e->members.as<int>(), md.M, Ns[l], lms[l].Np, md.bmember,
+                           lms[l].boff);
+        HCHECK(hipGetLastError());
+    }
+    if (d->normalizer != HIPETS_NORM_NONE) {
+        if (e->norm_mean.ensure((size_t)d->in_dim * 8) || e->norm_std.ensure((size_t)d->in_dim * 8)) return 1;
+        HCHECK(hipMemcpyAsync(e->norm_mean.p, d->norm_mean, (size_t)d->in_dim * 8, hipMemcpyHostToDevice, st));
+        HCHECK(hipMemcpyAsync(e->norm_std.p, d->norm_std, (size_t)d->in_dim * 8, hipMemcpyHostToDevice, st));
+    }
+    if (!d->deterministic) {
+        if (e->min_lv.ensure((size_t)d->out_dim * 4) || e->max_lv.ensure((size_t)d->out_dim * 4)) return 1;
+        HCHECK(hipMemcpyAsync(e->min_lv.p, d->min_logvar, (size_t)d->out_dim * 4, hipMemcpyHostToDevice, st));
+        HCHECK(hipMemcpyAsync(e->max_lv.p, d->max_logvar, (size_t)d->out_dim * 4, hipMemcpyHostToDevice, st));
+    }
+    std::vector<unsigned char> nd(d->obs_dim, 0);
+    for (int i = 0; i < d->n_no_delta; ++i) {
+        if (d->no_delta[i] < 0 || d->no_delta[i] >= d->obs_dim) return fail("no_delta index %d out of range", d->no_delta[i]);
+        nd[d->no_delta[i]] = 1;
+    }
+    if (e->no_delta.ensure((size_t)d->obs_dim)) return 1;
+    HCHECK(hipMemcpyAsync(e->no_delta.p, nd.data(), (size_t)d->obs_dim, hipMemcpyHostToDevice, st));
+    HCHECK(hipStreamSynchronize(st));  // host staging buffers (nd, caller arrays) may go away after return
+    md.layers = e->layer_meta.as<LayerMeta>();
+    md.w = e->wpack.as<float>();
+    md.b = e->bpack.as<float>();
+    md.norm_mean = e->norm_mean.as<double>();
+    md.norm_std = e->norm_std.as<double>();
+    md.min_lv = e->min_lv.as<float>();
+    md.max_lv = e->max_lv.as<float>();
+    md.no_delta = e->no_delta.as<unsigned char>();
+    e->md = md;
+    e->ensemble_size = d->ensemble_size;
+    e->has_model = true;
+    return 0;
+}
+
+int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t rows_per_group, int32_t* n_workgroups,
+                         int32_t* row_tiles) {
+    if (!e || !e->has_model) return fail("engine has no model");
+    if (pop < 1 || P < 1) return fail("bad pop/P");
+    if (rows_per_group < 0 || rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
+    const long long tiles = (pop + kTile - 1) / kTile;
+    const int R = choose_R(e, tiles, P, rows_per_group);
+    if (lds_for(e, R) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+    const long long groups = (tiles + R - 1) / R;
+    if (n_workgroups) *n_workgroups = (int)(groups * P);
+    if (row_tiles) *row_tiles = R;
+    return 0;
+}
+
+int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
+                   const hipets_rollout_opts* o, float* returns, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (!actions || !s0 || !o || !returns) return fail("null argument");
+    if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const ModelDev& md = e->md;
+    const long long B = (long long)pop * P;
+    if (B > 0x7FFFFFFF / std::max(md.obs_dim, md.out_dim)) return fail("batch too large");
+    if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
+
+    if (e->s0.ensure((size_t)md.obs_dim * 4)) return 1;
+    if (e->totals.ensure((size_t)B * 4)) return 1;
+    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)md.obs_dim * 4, hipMemcpyHostToDevice, st));
+
+    RolloutArgs ra{};
+    ra.pop = pop; ra.P = P; ra.H = H; ra.B = (int)B;
+    ra.mode = o->mode;
+    ra.actions = actions;
+    ra.s0 = e->s0.as<float>();
+    ra.totals = e->totals.as<float>();
+    ra.seed = o->seed;
+    ra.stream_id = o->stream_id;
+    ra.trace_next_obs = o->trace_next_obs;
+    ra.trace_rewards = o->trace_rewards;
+
+    if (o->mode == HIPETS_MODE_EXACT) {
+        const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
+        const int domains = expectation ? 1 : md.M;
+        if (!expectation) {
+            if (B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200)
+                return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
+                            "Current batch size is %lld for %d models.", B, md.M);
+            if (!o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
+        }
+        const int rpd = (int)(B / domains);
+        const long long tiles = (rpd + kTile - 1) / kTile;
+        const int R = choose_R(e, tiles, domains, o->rows_per_group);
+        const size_t lds = lds_for(e, R);
+        if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+        const int groups = (int)((tiles + R - 1) / R);
+        if (e->state.ensure((size_t)B * md.obs_dim * 4) || e->term.ensure((size_t)B)) return 1;
+        hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
+                           e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
+                           md.obs_dim);
+        HCHECK(hipGetLastError());
+        ra.groups = groups;
+        ra.rows_per_domain = rpd;
+        ra.state = e->state.as<float>();
+        ra.term = e->term.as<unsigned char>();
+        ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
+        ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? B : 0;
+        ra.eps = o->eps;
+        ra.use_philox = 0;
+        for (int t = 0; t < H; ++t) {
+            ra.t_begin = t;
+            ra.t_end = t + 1;
+            if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
+        }
+    } else if (o->mode == HIPETS_MODE_FAST) {
+        const long long tiles = (pop + kTile - 1) / kTile;
+        const int R = choose_R(e, tiles, P, o->rows_per_group);
+        const size_t lds = lds_for(e, R);
+        if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+        const int groups = (int)((tiles + R - 1) / R);
+        const int nwg = groups * P;
+        ra.groups = groups;
+        ra.eps = o->fast_eps;
+        ra.use_philox = o->fast_eps ? 0 : 1;
+        if (md.propagation != HIPETS_PROP_EXPECTATION) {
+            if (o->member_schedule) {
+                ra.schedule = o->member_schedule;
+            } else {
+                if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
+                hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), 0, st, e->schedule.as<int>(), nwg, md.M,
+                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)o->seed,
+                                   (unsigned long long)o->stream_id);
+                HCHECK(hipGetLastError());
+                ra.schedule = e->schedule.as<int>();
+            }
+        }
+        ra.t_begin = 0;
+        ra.t_end = H;
+        if (launch_rollout(e, R, nwg, lds, ra, st)) return 1;
+    } else {
+        return fail("unknown rollout mode %d", o->mode);
+    }
+    hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_cem_sample(hipets_engine* e, const hipets_cem_params* p, const float* mu, const float* dispersion,
+                      const float* lower, const float* upper, const float* z, uint64_t seed, uint64_t stream_id,
+                      float* population, void* stream) {
+    if (!e) return fail("null engine");
+    if (check_cem(p)) return 1;
+    if (!mu || !dispersion || !lower || !upper || !population) return fail("null argument");
+    HCHECK(hipSetDevice(e->device));
+    const CemDev c = make_cem(p);
+    const long long n = (long long)c.pop * c.D;
+    hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c,
+                       mu, dispersion, lower, upper, z, (unsigned long long)seed, (unsigned long long)stream_id, population);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values, const float* population, float* mu,
+                     float* dispersion, float* best_value, float* best_solution, int32_t* elite_idx, void* stream) {
+    if (!e) return fail("null engine");
+    if (check_cem(p)) return 1;
+    if (!values || !population || !mu || !dispersion || !best_value || !best_solution) return fail("null argument");
+    HCHECK(hipSetDevice(e->device));
+    const CemDev c = make_cem(p);
+    int n2 = 1;
+    while (n2 < c.pop) n2 <<= 1;
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8, reinterpret_cast<hipStream_t>(stream), c,
+                       values, population, mu, dispersion, best_value, best_solution, elite_idx);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
+                    const float* s0, int32_t P, uint64_t seed, uint64_t plan_id, float* out, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (check_cem(p)) return 1;
+    if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
+    if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const CemDev c = make_cem(p);
+    if (e->mu.ensure((size_t)c.D * 4) || e->disp.ensure((size_t)c.D * 4) || e->best_solution.ensure((size_t)c.D * 4) ||
+        e->best_value.ensure(16) || e->population.ensure((size_t)c.pop * c.D * 4) || e->values.ensure((size_t)c.pop * 4))
+        return 1;
+    hipLaunchKernelGGL(cem_init_kernel, dim3((c.D + 255) / 256), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
+                       e->disp.as<float>(), e->best_value.as<float>());
+    HCHECK(hipGetLastError());
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, (size_t)c.D * 4, st));
+    hipets_rollout_opts ro{};
+    ro.mode = HIPETS_MODE_FAST;
+    ro.seed = seed;
+    for (int i = 0; i < p->num_iterations; ++i) {
+        const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
+        if (hipets_cem_sample(e, p, e->mu.as<float>(), e->disp.as<float>(), lower, upper, nullptr, seed, sid,
+                              e->population.as<float>(), stream))
+            return 1;
+        ro.stream_id = sid;
+        if (hipets_rollout(e, e->population.as<float>(), s0, c.pop, c.H, P, &ro, e->values.as<float>(), stream)) return 1;
+        if (hipets_cem_refit(e, p, e->values.as<float>(), e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(),
+                             e->best_value.as<float>(), e->best_solution.as<float>(), nullptr, stream))
+            return 1;
+    }
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, (size_t)c.D * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int hipets_timing_enable(hipets_engine* e, int32_t on) {
+    if (!e) return fail("null engine");
+    e->timing = on != 0;
+    return 0;
+}
+
+int hipets_timing_read(hipets_engine* e, int64_t* launches, double* total_ms, int32_t reset) {
+    if (!e) return fail("null engine");
+    HCHECK(hipSetDevice(e->device));
+    double tot = 0.0;
+    for (auto& ev : e->events) {
+        HCHECK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HCHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+    }
+    if (launches) *launches = (int64_t)e->events.size();
+    if (total_ms) *total_ms = tot;
+    if (reset) {
+        for (auto& ev : e->events) e->event_pool.push_back(ev);
+        e->events.clear();
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""ctypes binding of libhipets.so (include/hipets.h).  No CPU fallback: if the shared library
+or a gfx950 device is missing, engine construction raises -- loudly, never silently."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhipets.so")
+
+ABI_VERSION = 1
+MAX_LAYERS = 8
+
+ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
+PROP = {"random_model": 0, "fixed_model": 1, "expectation": 2}
+OBS = {"none": 0, "halfcheetah": 1, "cartpole_pets": 2}
+REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendulum": 3, "halfcheetah": 4, "pusher": 5}
+TERM = {"no_termination": 0, "cartpole": 1, "inverted_pendulum": 2, "hopper": 3, "walker2d": 4, "ant": 5, "humanoid": 6}
+NORM = {"none": 0, "f32": 1, "f64": 2}
+MODE_EXACT, MODE_FAST = 0, 1
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32),
+        ("hid", C.c_int32), ("n_layers", C.c_int32), ("ensemble_size", C.c_int32), ("n_members", C.c_int32),
+        ("members", C.POINTER(C.c_int32)),
+        ("activation", C.c_int32), ("leaky_slope", C.c_float), ("propagation", C.c_int32),
+        ("deterministic", C.c_int32), ("obs_process", C.c_int32), ("reward_fn", C.c_int32),
+        ("termination_fn", C.c_int32), ("target_is_delta", C.c_int32), ("learned_rewards", C.c_int32),
+        ("n_no_delta", C.c_int32), ("no_delta", C.POINTER(C.c_int32)),
+        ("normalizer", C.c_int32), ("norm_mean", C.POINTER(C.c_double)), ("norm_std", C.POINTER(C.c_double)),
+        ("min_logvar", C.POINTER(C.c_float)), ("max_logvar", C.POINTER(C.c_float)),
+        ("weights", C.POINTER(C.c_void_p)), ("biases", C.POINTER(C.c_void_p)),
+    ]
+
+
+class RolloutOpts(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("perms", C.c_void_p), ("eps", C.c_void_p),
+        ("seed", C.c_uint64), ("stream_id", C.c_uint64),
+        ("member_schedule", C.c_void_p), ("fast_eps", C.c_void_p),
+        ("trace_next_obs", C.c_void_p), ("trace_rewards", C.c_void_p),
+        ("rows_per_group", C.c_int32),
+    ]
+
+
+class CemParams(C.Structure):
+    _fields_ = [
+        ("population_size", C.c_int32), ("horizon", C.c_int32), ("act_dim", C.c_int32),
+        ("num_iterations", C.c_int32), ("elite_num", C.c_int32), ("alpha", C.c_double),
+        ("return_mean_elites", C.c_int32), ("clipped_normal", C.c_int32), ("unbiased_var", C.c_int32),
+    ]
+
+
+# every symbol include/hipets.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "hipets_abi_version": (C.c_int, []),
+    "hipets_last_error": (C.c_char_p, []),
+    "hipets_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "hipets_destroy": (None, [_P]),
+    "hipets_set_model": (C.c_int, [_P, C.POINTER(ModelDesc), _P]),
+    "hipets_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RolloutOpts), _P, _P]),
+    "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hipets_plan_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
+    "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
+}
+
+_lib = None
+
+
+class HipetsError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libhipets.so and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipetsError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "hipets has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hipets_abi_version() != ABI_VERSION:
+        raise HipetsError(f"libhipets ABI {lib.hipets_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise HipetsError(load().hipets_last_error().decode())

@@ -1,0 +1,231 @@
+"""Engine: thin Python owner of one ``hipets_engine`` (one per GPU).  PyTorch is used only for
+device memory and streams; every computation is a libhipets call."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CemParams, HipetsError, ModelDesc, RolloutOpts
+from .model import ModelSpec
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_dev(t: torch.Tensor, dtype, device, name: str, shape=None):
+    if not isinstance(t, torch.Tensor) or t.device != device:
+        raise ValueError(f"{name} must be a tensor on {device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+class Engine:
+    """One fused planning engine bound to ``device`` (a gfx950 GPU).  Not thread-safe."""
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise HipetsError("hipets.Engine needs a GPU device (libhipets has no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.hipets_create(self.device.index, C.byref(h)))
+        self._h = h
+        self.spec: Optional[ModelSpec] = None
+        self._keep = []  # device tensors that must outlive async set_model work
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hipets_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model ------------------------------------------------------------------------------
+    def set_model(self, spec: ModelSpec):
+        spec.validate()
+        dev = self.device
+        ws = [w.detach().to(device=dev, dtype=torch.float32).contiguous() for w in spec.weights]
+        bs = [b.detach().to(device=dev, dtype=torch.float32).contiguous() for b in spec.biases]
+        n = len(ws)
+        members = spec.members
+        d = ModelDesc()
+        d.obs_dim, d.act_dim, d.in_dim, d.out_dim = spec.obs_dim, spec.act_dim, spec.in_dim, spec.out_dim
+        d.hid, d.n_layers, d.ensemble_size, d.n_members = spec.hid, n, spec.ensemble_size, len(members)
+        mem_arr = (C.c_int32 * len(members))(*members)
+        d.members = mem_arr
+        d.activation = _lib.ACT[spec.activation]
+        d.leaky_slope = float(spec.leaky_slope)
+        d.propagation = _lib.PROP[spec.propagation]
+        d.deterministic = int(spec.deterministic)
+        d.obs_process = _lib.OBS[spec.obs_process]
+        d.reward_fn = _lib.REW[spec.reward]
+        d.termination_fn = _lib.TERM[spec.termination]
+        d.target_is_delta = int(spec.target_is_delta)
+        d.learned_rewards = int(spec.learned_rewards)
+        nd = [int(i) for i in spec.no_delta_list]
+        nd_arr = (C.c_int32 * max(1, len(nd)))(*nd)
+        d.n_no_delta, d.no_delta = len(nd), nd_arr
+        if spec.norm_mean is not None:
+            d.normalizer = _lib.NORM["f64" if spec.norm_mean.dtype == torch.float64 else "f32"]
+            nm = np.ascontiguousarray(spec.norm_mean.detach().cpu().double().numpy().reshape(-1))
+            ns = np.ascontiguousarray(spec.norm_std.detach().cpu().double().numpy().reshape(-1))
+            d.norm_mean = nm.ctypes.data_as(C.POINTER(C.c_double))
+            d.norm_std = ns.ctypes.data_as(C.POINTER(C.c_double))
+        else:
+            d.normalizer = _lib.NORM["none"]
+        if not spec.deterministic:
+            lo = np.ascontiguousarray(spec.min_logvar.detach().cpu().float().numpy().reshape(-1))
+            hi = np.ascontiguousarray(spec.max_logvar.detach().cpu().float().numpy().reshape(-1))
+            d.min_logvar = lo.ctypes.data_as(C.POINTER(C.c_float))
+            d.max_logvar = hi.ctypes.data_as(C.POINTER(C.c_float))
+        w_arr = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+        b_arr = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        d.weights, d.biases = w_arr, b_arr
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_set_model(self._h, C.byref(d), _stream(dev)))
+        self.spec = spec
+
+    # ---- ModelEnv.evaluate_action_sequences ------------------------------------------------------
+    def rollout(self, actions: torch.Tensor, s0: np.ndarray, num_particles: int, *, mode: str = "fast",
+                perms: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, seed: int = 0,
+                stream_id: int = 0, member_schedule: Optional[torch.Tensor] = None,
+                trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
+                rows_per_group: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        if actions.ndim != 3:
+            raise ValueError("action_sequences must be [B, H, A]")
+        _check_dev(actions, torch.float32, dev, "action_sequences")
+        pop, H, A = actions.shape
+        if A != self.spec.act_dim:
+            raise ValueError(f"action dim {A} != model act_dim {self.spec.act_dim}")
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} dims, model obs_dim is {self.spec.obs_dim}")
+        B = pop * num_particles
+        o = RolloutOpts()
+        o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
+        if mode not in ("exact", "fast"):
+            raise ValueError("mode must be 'exact' or 'fast'")
+        if perms is not None:
+            _check_dev(perms, torch.int64, dev, "perms")
+            want = (B,) if self.spec.propagation == "fixed_model" else (H, B)
+            if tuple(perms.shape) != want:
+                raise ValueError(f"perms must have shape {want}")
+        if eps is not None:
+            _check_dev(eps, torch.float32, dev, "eps", (H, B, self.spec.out_dim))
+        if mode == "exact":
+            o.perms, o.eps = _ptr(perms), _ptr(eps)
+        else:
+            o.fast_eps = _ptr(eps)
+            if member_schedule is not None:
+                nwg, _ = self.fast_geometry(pop, num_particles, rows_per_group)
+                _check_dev(member_schedule, torch.int32, dev, "member_schedule", (H, nwg))
+                o.member_schedule = _ptr(member_schedule)
+        o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
+        if trace_next_obs is not None:
+            _check_dev(trace_next_obs, torch.float32, dev, "trace_next_obs", (H, B, self.spec.obs_dim))
+            o.trace_next_obs = _ptr(trace_next_obs)
+        if trace_rewards is not None:
+            _check_dev(trace_rewards, torch.float32, dev, "trace_rewards", (H, B))
+            o.trace_rewards = _ptr(trace_rewards)
+        o.rows_per_group = int(rows_per_group)
+        if out is None:
+            out = torch.empty(pop, dtype=torch.float32, device=dev)
+        else:
+            _check_dev(out, torch.float32, dev, "out", (pop,))
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_rollout(self._h, _ptr(actions), s0.ctypes.data_as(C.c_void_p), pop, H,
+                                                num_particles, C.byref(o), _ptr(out), _stream(dev)))
+        return out
+
+    def fast_geometry(self, pop: int, num_particles: int, rows_per_group: int = 0):
+        nwg, r = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.hipets_fast_geometry(self._h, pop, num_particles, rows_per_group, C.byref(nwg), C.byref(r)))
+        return nwg.value, r.value
+
+    # ---- optimizer pieces ---------------------------------------------------------------------------
+    @staticmethod
+    def cem_params(population_size, horizon, act_dim, num_iterations, elite_num, alpha, return_mean_elites=False,
+                   clipped_normal=False, unbiased_var=True) -> CemParams:
+        p = CemParams()
+        p.population_size, p.horizon, p.act_dim = int(population_size), int(horizon), int(act_dim)
+        p.num_iterations, p.elite_num, p.alpha = int(num_iterations), int(elite_num), float(alpha)
+        p.return_mean_elites, p.clipped_normal, p.unbiased_var = int(return_mean_elites), int(clipped_normal), int(unbiased_var)
+        return p
+
+    def cem_sample(self, p: CemParams, mu, dispersion, lower, upper, population, z=None, seed=0, stream_id=0):
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("mu", mu), ("dispersion", dispersion), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        _check_dev(population, torch.float32, dev, "population", (p.population_size,) + shp)
+        if z is not None:
+            _check_dev(z, torch.float32, dev, "z", (p.population_size,) + shp)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_cem_sample(self._h, C.byref(p), _ptr(mu), _ptr(dispersion), _ptr(lower), _ptr(upper),
+                                                   _ptr(z), int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1),
+                                                   _ptr(population), _stream(dev)))
+        return population
+
+    def cem_refit(self, p: CemParams, values, population, mu, dispersion, best_value, best_solution, elite_idx=None):
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        _check_dev(values, torch.float32, dev, "values", (p.population_size,))
+        _check_dev(population, torch.float32, dev, "population", (p.population_size,) + shp)
+        for n_, t in (("mu", mu), ("dispersion", dispersion), ("best_solution", best_solution)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        _check_dev(best_value, torch.float32, dev, "best_value", (1,))
+        if elite_idx is not None:
+            _check_dev(elite_idx, torch.int32, dev, "elite_idx", (p.elite_num,))
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_cem_refit(self._h, C.byref(p), _ptr(values), _ptr(population), _ptr(mu), _ptr(dispersion),
+                                                  _ptr(best_value), _ptr(best_solution), _ptr(elite_idx), _stream(dev)))
+
+    def plan_cem(self, p: CemParams, x0, lower, upper, s0: np.ndarray, num_particles: int, seed: int = 0,
+                 plan_id: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} dims, model obs_dim is {self.spec.obs_dim}")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_cem(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper),
+                                                 s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                 int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
+    # ---- instrumentation ---------------------------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        _lib.check(self._lib.hipets_timing_enable(self._h, int(on)))
+
+    def timing_read(self, reset: bool = True):
+        n, ms = C.c_int64(), C.c_double()
+        _lib.check(self._lib.hipets_timing_read(self._h, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value

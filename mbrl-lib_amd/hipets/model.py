@@ -1,0 +1,176 @@
+"""ModelSpec: the snapshot of a PETS dynamics model the engine consumes, and its extraction from
+live mbrl-lib objects (duck-typed -- mbrl itself is never imported here).
+
+Mirrors what ModelEnv.evaluate_action_sequences reads:
+``model_env.dynamics_model`` (OneDTransitionRewardModel, mbrl/models/one_dim_tr_model.py:29-116) ->
+``.model`` (GaussianMLP, mbrl/models/gaussian_mlp.py:69-127), normaliser (mbrl/util/math.py:95-143),
+``model_env.reward_fn`` / ``.termination_fn`` (mbrl/env/reward_fns.py, termination_fns.py).
+Anything the fused kernel cannot express raises UnsupportedModelError so that callers fall back to
+the reference path instead of silently approximating.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+
+class UnsupportedModelError(ValueError):
+    pass
+
+
+_ACT_BY_CLASS = {"SiLU": "silu", "ReLU": "relu", "LeakyReLU": "leaky_relu", "Tanh": "tanh", "Sigmoid": "sigmoid"}
+_KNOWN_REWARDS = ("cartpole", "cartpole_pets", "inverted_pendulum", "halfcheetah", "pusher")
+_KNOWN_TERMS = ("no_termination", "cartpole", "inverted_pendulum", "hopper", "walker2d", "ant", "humanoid")
+
+
+@dataclass
+class ModelSpec:
+    weights: List[torch.Tensor]  # per linear layer [E, in_l, out_l] f32
+    biases: List[torch.Tensor]  # per linear layer [E, 1, out_l] f32
+    obs_dim: int
+    act_dim: int
+    min_logvar: Optional[torch.Tensor] = None  # [1, out]
+    max_logvar: Optional[torch.Tensor] = None
+    elite_models: Optional[Sequence[int]] = None
+    activation: str = "silu"
+    leaky_slope: float = 0.01
+    propagation: str = "random_model"
+    deterministic: bool = False
+    norm_mean: Optional[torch.Tensor] = None  # [1, in] f32 / f64
+    norm_std: Optional[torch.Tensor] = None
+    target_is_delta: bool = True
+    no_delta_list: Sequence[int] = field(default_factory=list)
+    learned_rewards: bool = False
+    obs_process: str = "none"
+    reward: Optional[str] = "halfcheetah"  # None => learned reward (last model output)
+    termination: str = "no_termination"
+
+    # ---- derived ---------------------------------------------------------------------------
+    @property
+    def ensemble_size(self) -> int:
+        return int(self.weights[0].shape[0])
+
+    @property
+    def in_dim(self) -> int:
+        return int(self.weights[0].shape[1])
+
+    @property
+    def hid(self) -> int:
+        return int(self.weights[0].shape[2])
+
+    @property
+    def out_dim(self) -> int:
+        n = int(self.weights[-1].shape[2])
+        return n if self.deterministic else n // 2
+
+    @property
+    def members(self) -> List[int]:
+        if self.elite_models is not None:
+            return [int(i) for i in self.elite_models]
+        return list(range(self.ensemble_size))
+
+    def flops_per_candidate_step(self) -> int:
+        """2 * (in*hid + (L-1)*hid^2 + hid*out_total)."""
+        return 2 * sum(int(w.shape[1]) * int(w.shape[2]) for w in self.weights)
+
+    def validate(self):
+        if self.activation not in _ACT_BY_CLASS.values():
+            raise UnsupportedModelError(f"activation {self.activation!r} has no fused implementation")
+        if self.propagation not in ("random_model", "fixed_model", "expectation"):
+            raise ValueError(f"Invalid propagation method {self.propagation}.")  # gaussian_mlp.py:216
+        if self.reward is not None and self.reward not in _KNOWN_REWARDS:
+            raise UnsupportedModelError(f"reward_fn {self.reward!r} has no fused implementation")
+        if self.reward is None and not self.learned_rewards:
+            raise UnsupportedModelError("reward_fn is None but the model does not learn rewards")
+        if self.termination not in _KNOWN_TERMS:
+            raise UnsupportedModelError(f"termination_fn {self.termination!r} has no fused implementation")
+        if self.obs_process not in ("none", "halfcheetah", "cartpole_pets"):
+            raise UnsupportedModelError(f"obs_process_fn {self.obs_process!r} has no fused implementation")
+        if len(self.weights) < 2 or len(self.weights) > 8:
+            raise UnsupportedModelError("need 2..8 linear layers")
+        for li in range(1, len(self.weights) - 1):
+            if tuple(self.weights[li].shape[1:]) != (self.hid, self.hid):
+                raise UnsupportedModelError("hidden layers must share one width")
+        exp_in = self.obs_dim + (1 if self.obs_process == "cartpole_pets" else 0) + self.act_dim
+        if self.in_dim != exp_in:
+            raise UnsupportedModelError(f"model in_size {self.in_dim} != obs'+act = {exp_in}")
+        if self.out_dim != self.obs_dim + (1 if self.learned_rewards else 0):
+            raise UnsupportedModelError("model out_size inconsistent with obs_dim / learned_rewards")
+
+
+def _fn_name(fn) -> Optional[str]:
+    if fn is None:
+        return None
+    return getattr(fn, "__name__", None)
+
+
+def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optional[int] = None) -> ModelSpec:
+    """Read a live ``mbrl.models.ModelEnv`` (or anything shaped like it).  No copy of the big tensors:
+    the spec holds references to the live parameters; ``Engine.set_model`` packs them on device."""
+    dm = model_env.dynamics_model
+    mlp = getattr(dm, "model", None)
+    if mlp is None or not hasattr(mlp, "hidden_layers") or not hasattr(mlp, "mean_and_logvar"):
+        raise UnsupportedModelError("dynamics_model.model is not a GaussianMLP-shaped ensemble")
+    ws, bs = [], []
+    act_name = None
+    for layer in mlp.hidden_layers:
+        lin, act = layer[0], layer[1]
+        if not getattr(lin, "use_bias", True):
+            raise UnsupportedModelError("EnsembleLinearLayer without bias")
+        ws.append(lin.weight.detach())
+        bs.append(lin.bias.detach())
+        name = _ACT_BY_CLASS.get(type(act).__name__)
+        if name is None:
+            raise UnsupportedModelError(f"activation module {type(act).__name__} has no fused implementation")
+        if act_name is not None and name != act_name:
+            raise UnsupportedModelError("mixed activation modules")
+        act_name = name
+        slope = float(getattr(act, "negative_slope", 0.01))
+    ws.append(mlp.mean_and_logvar.weight.detach())
+    bs.append(mlp.mean_and_logvar.bias.detach())
+    if ws[0].ndim != 3:
+        raise UnsupportedModelError("expected ensemble weights [E, in, out]")
+    deterministic = bool(getattr(mlp, "deterministic", False))
+    norm = getattr(dm, "input_normalizer", None)
+    obs_fn = getattr(dm, "obs_process_fn", None)
+    obs_process = "none"
+    if obs_fn is not None:
+        q = getattr(obs_fn, "__qualname__", "")
+        if "HalfCheetahEnv" in q:
+            obs_process = "halfcheetah"
+        elif "CartPoleEnv" in q:
+            obs_process = "cartpole_pets"
+        else:
+            raise UnsupportedModelError(f"obs_process_fn {q!r} has no fused implementation")
+    od = obs_dim if obs_dim is not None else int(model_env.observation_space.shape[0])
+    ad = act_dim if act_dim is not None else int(model_env.action_space.shape[0])
+    rew = model_env.reward_fn
+    spec = ModelSpec(
+        weights=ws, biases=bs, obs_dim=od, act_dim=ad,
+        min_logvar=None if deterministic else mlp.min_logvar.detach(),
+        max_logvar=None if deterministic else mlp.max_logvar.detach(),
+        elite_models=list(mlp.elite_models) if getattr(mlp, "elite_models", None) is not None else None,
+        activation=act_name or "relu", leaky_slope=slope,
+        propagation=mlp.propagation_method, deterministic=deterministic,
+        norm_mean=norm.mean.detach() if norm is not None else None,
+        norm_std=norm.std.detach() if norm is not None else None,
+        target_is_delta=bool(dm.target_is_delta), no_delta_list=list(dm.no_delta_list or []),
+        learned_rewards=bool(dm.learned_rewards), obs_process=obs_process,
+        reward=_fn_name(rew), termination=_fn_name(model_env.termination_fn),
+    )
+    spec.validate()
+    return spec
+
+
+def model_version(model_env) -> tuple:
+    """Cheap freshness token: changes when ModelTrainer.train rewrote weights / normaliser / elites
+    (mbrl/models/model_trainer.py:288-296)."""
+    dm = model_env.dynamics_model
+    mlp = dm.model
+    vers = tuple(int(p._version) for p in mlp.parameters())
+    norm = getattr(dm, "input_normalizer", None)
+    nid = (id(norm.mean), id(norm.std)) if norm is not None else ()
+    el = tuple(mlp.elite_models) if getattr(mlp, "elite_models", None) is not None else None
+    return (vers, nid, el, getattr(mlp, "propagation_method", None))

@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY: build the *unmodified reference classes* from an OracleModel.
+
+Works only where /root/reference is mounted (this build container).  It puts the stand-in
+modules of ``oracle/ref_stubs`` (hydra / omegaconf / gymnasium / termcolor -- absent here, no
+network) and the reference root on ``sys.path`` and imports ``mbrl`` untouched.  Used by
+``oracle/make_golden.py`` and ``tests/test_oracle_vs_reference.py``; never by the product, the
+GPU tests, smoke() or bench.py (the reference does not exist on the GPU box).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = os.environ.get("HIPETS_REFERENCE_ROOT", "/root/reference")
+_STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "mbrl"))
+
+
+def import_reference():
+    if not reference_available():
+        raise RuntimeError(f"reference not mounted at {REFERENCE_ROOT}")
+    for p in (REFERENCE_ROOT, _STUBS):
+        if p in sys.path:
+            sys.path.remove(p)
+    sys.path.insert(0, REFERENCE_ROOT)
+    sys.path.insert(0, _STUBS)
+    import mbrl.models  # noqa: F401
+    import mbrl.planning  # noqa: F401
+    import mbrl.util.math  # noqa: F401
+    import mbrl  # noqa: F401
+
+    return mbrl
+
+
+_ACT_TARGET = {
+    "silu": "torch.nn.SiLU",
+    "relu": "torch.nn.ReLU",
+    "leaky_relu": "torch.nn.LeakyReLU",
+    "tanh": "torch.nn.Tanh",
+    "sigmoid": "torch.nn.Sigmoid",
+}
+
+
+class _FakeEnv:
+    def __init__(self, obs_dim, act_dim, lo=-1.0, hi=1.0):
+        import gymnasium as gym
+
+        self.observation_space = gym.spaces.Box(-np.inf, np.inf, shape=(obs_dim,))
+        self.action_space = gym.spaces.Box(lo, hi, shape=(act_dim,))
+
+
+def build_reference_model_env(om, obs_dim: int, act_dim: int, generator=None):
+    """OracleModel -> (mbrl.models.ModelEnv, OneDTransitionRewardModel, GaussianMLP)."""
+    mbrl = import_reference()
+    from mbrl.env import reward_fns, termination_fns
+    import mbrl.env.pets_halfcheetah  # noqa: F401  (needs the gymnasium stand-in only)
+
+    E = om.weights[0].shape[0]
+    in_size = om.weights[0].shape[1]
+    hid = om.weights[0].shape[2]
+    out_total = om.weights[-1].shape[2]
+    out_size = out_total if om.deterministic else out_total // 2
+    model = mbrl.models.GaussianMLP(
+        in_size, out_size, "cpu", num_layers=len(om.weights) - 1, ensemble_size=E, hid_size=hid,
+        deterministic=om.deterministic, propagation_method=om.propagation,
+        activation_fn_cfg={"_target_": _ACT_TARGET[om.activation]},
+    )
+    with torch.no_grad():
+        for li in range(len(om.weights) - 1):
+            model.hidden_layers[li][0].weight.copy_(om.weights[li])
+            model.hidden_layers[li][0].bias.copy_(om.biases[li])
+        model.mean_and_logvar.weight.copy_(om.weights[-1])
+        model.mean_and_logvar.bias.copy_(om.biases[-1])
+        if not om.deterministic:
+            model.min_logvar.copy_(om.min_logvar)
+            model.max_logvar.copy_(om.max_logvar)
+    if om.elite_models is not None:
+        model.set_elite(list(om.elite_models))
+    obs_fn = None
+    if om.obs_process == "halfcheetah":
+        from mbrl.env.pets_halfcheetah import HalfCheetahEnv
+
+        obs_fn = HalfCheetahEnv.preprocess_fn
+    elif om.obs_process == "cartpole_pets":
+        from mbrl.env.pets_cartpole import CartPoleEnv
+
+        obs_fn = CartPoleEnv.preprocess_fn
+    dm = mbrl.models.OneDTransitionRewardModel(
+        model, target_is_delta=om.target_is_delta, normalize=om.norm_mean is not None,
+        normalize_double_precision=(om.norm_mean is not None and om.norm_mean.dtype == torch.float64),
+        learned_rewards=om.learned_rewards, obs_process_fn=obs_fn,
+        no_delta_list=list(om.no_delta_list) if om.no_delta_list else None,
+    )
+    if om.norm_mean is not None:
+        dm.input_normalizer.mean = om.norm_mean.clone()
+        dm.input_normalizer.std = om.norm_std.clone()
+    reward_fn = getattr(reward_fns, om.reward) if om.reward is not None else None
+    term_fn = getattr(termination_fns, om.termination)
+    env = _FakeEnv(obs_dim, act_dim)
+    me = mbrl.models.ModelEnv(env, dm, term_fn, reward_fn, generator=generator)
+    return me, dm, model
