@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- candidate-steps/sec of the PETS planning hot path on MI355X (BASELINE.json metric).
+
+A "step" is ONE PLAN: the whole CEMOptimizer.optimize loop (5 iterations x pop 500 x 20 particles x
+horizon 30 rollouts through the 5-member GaussianMLP ensemble + elite refit) = what
+TrajectoryOptimizerAgent.act does per environment step, on BASELINE.json configs[1]
+("PETS HalfCheetah (obs=17, act=6), ensemble=5, CEM pop=500, horizon=30, particles=20").
+Inputs (weights, s0, bounds) are resident in HBM before the timed region; synthetic random-init
+weights (reference initialiser), fp32 arithmetic end to end (fp64 input normaliser like the reference).
+
+    python bench.py [--gpus N --steps K --warmup W]        # N>1: launched by torch.distributed.run
+
+N>1 = configs[2]: the SAME population sharded over N ranks (strong scaling), replicated sampling, one
+RCCL all-gather of the candidate returns per CEM iteration.  `--scaling weak` keeps pop 500 per rank.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mbrl-lib_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+OBS, ACT, ENSEMBLE, HID, LAYERS = 17, 6, 5, 200, 4
+POP, HORIZON, PARTICLES, ITERS, ELITE_RATIO, ALPHA = 500, 30, 20, 5, 0.1, 0.1
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
+
+
+def synthetic_spec(device):
+    """Random-init GaussianMLP ensemble with the reference initialiser (models/util.py:15-28: truncated
+    normal std 1/(2 sqrt(in)), zero bias; logvar bounds -10 / 0.5), built on the product side (no oracle)."""
+    import hipets
+
+    g = torch.Generator().manual_seed(0)
+    dims = [OBS + ACT] + [HID] * LAYERS + [2 * OBS]
+    ws, bs = [], []
+    for i in range(len(dims) - 1):
+        std = 1.0 / (2.0 * np.sqrt(dims[i]))
+        w = torch.empty(ENSEMBLE, dims[i], dims[i + 1])
+        torch.nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+        ws.append(w.to(device))
+        bs.append(torch.zeros(ENSEMBLE, 1, dims[i + 1], device=device))
+    return hipets.ModelSpec(
+        weights=ws, biases=bs, obs_dim=OBS, act_dim=ACT, min_logvar=-10 * torch.ones(1, OBS), max_logvar=0.5 * torch.ones(1, OBS),
+        activation="silu", propagation="random_model", norm_mean=torch.zeros(1, OBS + ACT, dtype=torch.float64),
+        norm_std=torch.ones(1, OBS + ACT, dtype=torch.float64), target_is_delta=True, learned_rewards=False,
+        reward="halfcheetah", termination="no_termination")
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's algorithm on this box's host cores: the oracle (a torch-CPU restatement that is bitwise
+    equal to mbrl-lib's ModelEnv + CEMOptimizer, see oracle/) timed on a BOUNDED sample of the cfg2 workload.
+    Checker code, used here ONLY as the reported baseline, never by the product path.
+
+    The per-step cost of evaluate_action_sequences does not depend on the step index, so the sample is cfg2's
+    full batch (pop 500 x 20 particles) rolled for a shortened horizon sized to fit the time budget; the thread
+    count is calibrated first (torch's default of one thread per logical core can be catastrophically slow)."""
+    from oracle import pets_oracle as po
+
+    om = po.make_synthetic_model(OBS, ACT, ensemble_size=ENSEMBLE, hid=HID, num_layers=LAYERS, seed=0, nontrivial_stats=False)
+    s0 = (np.random.default_rng(0).standard_normal(OBS) * 0.1).astype(np.float32)
+    gen = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+
+    def run(h):
+        acts = torch.rand(POP, h, ACT, generator=g) * 2 - 1
+        t0 = time.perf_counter()
+        po.rollout(om, acts, s0, PARTICLES, global_rng=True, generator=gen)
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    usable = _usable_cores()
+    best_threads, best_t = 1, None
+    for nt in sorted({1, min(8, usable), min(16, usable), min(32, usable), min(64, usable)}):
+        torch.set_num_threads(nt)
+        run(1)  # warm-up for this thread count
+        t = min(run(1), run(1))
+        if best_t is None or t < best_t:
+            best_threads, best_t = nt, t
+        if time.perf_counter() - t_start > 0.4 * budget_s:
+            break
+    torch.set_num_threads(best_threads)
+    remaining = max(1.0, budget_s - (time.perf_counter() - t_start))
+    h = int(max(1, min(HORIZON, remaining / 2 / best_t)))
+    reps = int(max(2, min(6, remaining / (h * best_t))))
+    times = [run(h) for _ in range(reps)]
+    cs = POP * PARTICLES * h
+    v = cs / min(times)
+    return {"value": v, "unit": "candidate-steps/s", "cores": best_threads, "kind": "port",
+            "sample": f"{reps} x evaluate_action_sequences on cfg2's batch (pop {POP} x {PARTICLES} particles) for {h} of {HORIZON} "
+                      f"horizon steps ({cs} candidate-steps), min time; thread count calibrated over <= {usable} usable "
+                      f"cores; torch {torch.__version__} CPU",
+            "plans_per_s_extrapolated": v / (ITERS * POP * PARTICLES * HORIZON)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import hipets
+    from hipets import dist as hdist
+    from hipets.planning import _BoundObjective
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    engine = hipets.get_engine(device)
+    spec = synthetic_spec(device)
+    pop = POP * world if (world > 1 and args.scaling == "weak") else POP
+    eval_fn = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0)
+    lb, ub = [[-1.0] * ACT] * HORIZON, [[1.0] * ACT] * HORIZON
+    opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
+    s0 = (np.random.default_rng(0).standard_normal(OBS) * 0.1).astype(np.float32)
+    x0 = torch.zeros(HORIZON, ACT, device=device)
+    if world > 1:
+        objective = _BoundObjective(hdist.ShardedEvalFn(eval_fn), s0)  # generic path + one all-gather per iteration
+    else:
+        objective = _BoundObjective(eval_fn, s0)  # fused hipets_plan_cem
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        opt.optimize(objective, x0=x0)
+    engine.timing_enable(True)
+    engine.timing_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sol = opt.optimize(objective, x0=x0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = engine.timing_read(reset=True)
+    engine.timing_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(sol).all()
+
+    cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
+    value = args.steps * cand_steps_per_plan / elapsed
+    flops_cs = spec.flops_per_candidate_step()
+    # dominant kernel = rollout_kernel: one launch rolls (pop / world) candidates x P particles x H steps
+    local_pop = pop // world if world > 1 else pop
+    alg_flops_per_launch = flops_cs * local_pop * PARTICLES * HORIZON
+    avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
+    achieved = alg_flops_per_launch / avg_launch_s / 1e12 if launches else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("rollout_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "candidate-steps/sec (pop x particles x horizon / plan) per CEM iter; plans/sec",
+        "value": value, "unit": "candidate-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: PETS HalfCheetah obs=17 act=6, GaussianMLP ensemble=5 (4x200 SiLU, TS1), "
+                               f"CEM pop={pop} horizon={HORIZON} particles={PARTICLES} iters={ITERS}; one step = one plan "
+                               "(TrajectoryOptimizerAgent.act)",
+                   "candidate_steps_per_plan": cand_steps_per_plan, "plans_per_s": args.steps / elapsed,
+                   "parallelism": f"population-sharded x{world}" if world > 1 else "single GPU, fused plan",
+                   "mode": "FAST (in-kernel Philox, block-balanced TS1)"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (achieved / PEAK_FP32_TFLOPS) if achieved else None, "traffic": traffic,
+                     "kernel": "hipets::rollout_kernel", "launches": launches,
+                     "avg_launch_ms": 1e3 * avg_launch_s if launches else None,
+                     "algorithmic_flops_per_launch": alg_flops_per_launch, "flops_per_candidate_step": flops_cs},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+            out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

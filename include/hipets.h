@@ -124,9 +124,20 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
 int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t rows_per_group,
                          int32_t* n_workgroups, int32_t* row_tiles);
 
+/* FAST-mode randomness, exported so a FAST rollout can be replayed through a reference implementation:
+ * schedule DEVICE int32 [H, n_workgroups] = member slot of workgroup w at step t (workgroup w owns particle
+ * w % P of candidates [(w / P) * 16 * row_tiles, ...)); normals DEVICE f32 [H, B, out_dim] = the eps the kernel
+ * draws for (step, row, dim) with the same (seed, stream_id).                                                */
+int hipets_fast_schedule(hipets_engine* e, int32_t horizon, int32_t n_workgroups, uint64_t seed, uint64_t stream_id,
+                         int32_t* schedule, void* stream);
+int hipets_fast_normals(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id,
+                        float* normals, void* stream);
+
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {
-    int32_t population_size, horizon, act_dim;
+    int32_t population_size;
+    int32_t horizon;
+    int32_t act_dim;
     int32_t num_iterations;
     int32_t elite_num;          /* ceil(pop * elite_ratio), trajectory_opt.py:89-91             */
     double alpha;               /* momentum; (1 - alpha) is formed in double like the Python reference */

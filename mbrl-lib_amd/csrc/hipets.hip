@@ -373,10 +373,10 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     if (o->mode == HIPETS_MODE_EXACT) {
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
+        if (B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
+            return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
+                        "Current batch size is %lld for %d models.", B, md.M);
         if (!expectation) {
-            if (B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200)
-                return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
-                            "Current batch size is %lld for %d models.", B, md.M);
             if (!o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
         }
         const int rpd = (int)(B / domains);
@@ -432,6 +432,29 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         return fail("unknown rollout mode %d", o->mode);
     }
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_fast_schedule(hipets_engine* e, int32_t H, int32_t nwg, uint64_t seed, uint64_t stream_id, int32_t* schedule,
+                         void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model");
+    if (!schedule || H < 1 || nwg < 1) return fail("bad argument");
+    HCHECK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
+                       e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)seed,
+                       (unsigned long long)stream_id);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_fast_normals(hipets_engine* e, int32_t H, int32_t B, uint64_t seed, uint64_t stream_id, float* normals, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model");
+    if (!normals || H < 1 || B < 1) return fail("bad argument");
+    HCHECK(hipSetDevice(e->device));
+    const long long n = (long long)H * B * ((e->md.out_dim + 3) / 4);
+    hipLaunchKernelGGL(export_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       normals, H, B, e->md.out_dim, (unsigned long long)seed, (unsigned long long)stream_id);
     HCHECK(hipGetLastError());
     return 0;
 }

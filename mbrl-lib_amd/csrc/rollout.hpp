@@ -286,6 +286,15 @@ __device__ __forceinline__ float reward_eval(const float* s, const float* a, int
     }
 }
 
+// the 4 standard normals of (row, step, dim block): counter = (row, step, block, stream), key = seed
+__device__ __forceinline__ void rollout_normals4(int rid, int t, int blk, unsigned long long seed,
+                                                 unsigned long long stream_id, float (&nrm)[4]) {
+    const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)blk, (uint32_t)stream_id, (uint32_t)seed,
+                                     (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32));
+    box_muller(r4.x, r4.y, nrm[0], nrm[1]);
+    box_muller(r4.z, r4.w, nrm[2], nrm[3]);
+}
+
 struct RolloutSmem {
     float* buf0;
     float* buf1;
@@ -449,10 +458,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                         if (d < md.out_dim) nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
                     }
                 } else if (ra.use_philox) {
-                    const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)blk, (uint32_t)ra.stream_id,
-                                                     (uint32_t)ra.seed, (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32));
-                    box_muller(r4.x, r4.y, nrm[0], nrm[1]);
-                    box_muller(r4.z, r4.w, nrm[2], nrm[3]);
+                    rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
                 }
             }
 #pragma unroll
@@ -552,6 +558,23 @@ __global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, un
             rank += (ki < kme) || (ki == kme && i < me);
         }
         sched[(size_t)t * nwg + me] = (int)(((long long)rank * M) / nwg);
+    }
+}
+
+// export of the FAST-mode normals (hipets_fast_normals): out[t][rid][d]
+__global__ void export_normals_kernel(float* out, int H, int B, int out_dim, unsigned long long seed,
+                                      unsigned long long stream_id) {
+    const int nblk = (out_dim + 3) / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * B * nblk) return;
+    const int blk = (int)(i % nblk);
+    const int rid = (int)((i / nblk) % B);
+    const int t = (int)(i / ((long long)nblk * B));
+    float nrm[4];
+    rollout_normals4(rid, t, blk, seed, stream_id, nrm);
+    for (int q = 0; q < 4; ++q) {
+        const int d = blk * 4 + q;
+        if (d < out_dim) out[((size_t)t * B + rid) * out_dim + d] = nrm[q];
     }
 }
 

@@ -1,12 +1,24 @@
 """hipets -- MI355X-native PETS planning / rollout engine behind mbrl-lib's own plugin seams.
 
-Public surface (names follow mbrl-lib so the stock Hydra configs only swap ``_target_``):
-``Engine``, ``ModelSpec``, ``spec_from_model_env``, and (planning.py) ``CEMOptimizer``,
-``TrajectoryOptimizer``, ``TrajectoryOptimizerAgent``, ``make_eval_fn``,
-``create_trajectory_optim_agent_for_model``.
+Public names follow mbrl-lib so the stock Hydra configs only swap ``_target_``:
+``hipets.TrajectoryOptimizerAgent``, ``hipets.CEMOptimizer`` ... or, on a stock agent,
+``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))``.
 """
 from ._lib import HipetsError, LIB_PATH  # noqa: F401
 from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_model_env  # noqa: F401
 from .engine import Engine  # noqa: F401
+from .planning import (  # noqa: F401
+    Agent,
+    CEMOptimizer,
+    HipTrajectoryEvalFn,
+    Optimizer,
+    TrajectoryOptimizer,
+    TrajectoryOptimizerAgent,
+    complete_agent_cfg,
+    create_trajectory_optim_agent_for_model,
+    get_engine,
+    make_eval_fn,
+)
+from . import dist  # noqa: F401
 
 __version__ = "0.1.0"

@@ -64,6 +64,8 @@ SYMBOLS = {
     "hipets_set_model": (C.c_int, [_P, C.POINTER(ModelDesc), _P]),
     "hipets_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RolloutOpts), _P, _P]),
     "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hipets_fast_schedule": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
     "hipets_plan_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),

@@ -21,7 +21,7 @@ def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _check_dev(t: torch.Tensor, dtype, device, name: str, shape=None):
+def _check_dev(t: torch.Tensor, dtype, device, name: str, shape=None, numel=None):
     if not isinstance(t, torch.Tensor) or t.device != device:
         raise ValueError(f"{name} must be a tensor on {device}")
     if t.dtype != dtype:
@@ -30,6 +30,8 @@ def _check_dev(t: torch.Tensor, dtype, device, name: str, shape=None):
         raise ValueError(f"{name} must be contiguous")
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name} must have {numel} elements, got {t.numel()}")
 
 
 class Engine:
@@ -164,6 +166,22 @@ class Engine:
         _lib.check(self._lib.hipets_fast_geometry(self._h, pop, num_particles, rows_per_group, C.byref(nwg), C.byref(r)))
         return nwg.value, r.value
 
+    def fast_schedule(self, horizon: int, n_workgroups: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:
+        """The member schedule a FAST rollout with (seed, stream_id) uses: int32 [H, n_workgroups]."""
+        out = torch.empty(horizon, n_workgroups, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hipets_fast_schedule(self._h, horizon, n_workgroups, int(seed) & (2**64 - 1),
+                                                      int(stream_id) & (2**64 - 1), _ptr(out), _stream(self.device)))
+        return out
+
+    def fast_normals(self, horizon: int, batch: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:
+        """The eps a FAST rollout with (seed, stream_id) draws: f32 [H, B, out_dim]."""
+        out = torch.empty(horizon, batch, self.spec.out_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hipets_fast_normals(self._h, horizon, batch, int(seed) & (2**64 - 1),
+                                                     int(stream_id) & (2**64 - 1), _ptr(out), _stream(self.device)))
+        return out
+
     # ---- optimizer pieces ---------------------------------------------------------------------------
     @staticmethod
     def cem_params(population_size, horizon, act_dim, num_iterations, elite_num, alpha, return_mean_elites=False,
@@ -176,12 +194,12 @@ class Engine:
 
     def cem_sample(self, p: CemParams, mu, dispersion, lower, upper, population, z=None, seed=0, stream_id=0):
         dev = self.device
-        shp = (p.horizon, p.act_dim)
+        D = p.horizon * p.act_dim
         for n_, t in (("mu", mu), ("dispersion", dispersion), ("lower", lower), ("upper", upper)):
-            _check_dev(t, torch.float32, dev, n_, shp)
-        _check_dev(population, torch.float32, dev, "population", (p.population_size,) + shp)
+            _check_dev(t, torch.float32, dev, n_, numel=D)
+        _check_dev(population, torch.float32, dev, "population", numel=p.population_size * D)
         if z is not None:
-            _check_dev(z, torch.float32, dev, "z", (p.population_size,) + shp)
+            _check_dev(z, torch.float32, dev, "z", numel=p.population_size * D)
         with torch.cuda.device(dev):
             _lib.check(self._lib.hipets_cem_sample(self._h, C.byref(p), _ptr(mu), _ptr(dispersion), _ptr(lower), _ptr(upper),
                                                    _ptr(z), int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1),
@@ -190,11 +208,11 @@ class Engine:
 
     def cem_refit(self, p: CemParams, values, population, mu, dispersion, best_value, best_solution, elite_idx=None):
         dev = self.device
-        shp = (p.horizon, p.act_dim)
+        D = p.horizon * p.act_dim
         _check_dev(values, torch.float32, dev, "values", (p.population_size,))
-        _check_dev(population, torch.float32, dev, "population", (p.population_size,) + shp)
+        _check_dev(population, torch.float32, dev, "population", numel=p.population_size * D)
         for n_, t in (("mu", mu), ("dispersion", dispersion), ("best_solution", best_solution)):
-            _check_dev(t, torch.float32, dev, n_, shp)
+            _check_dev(t, torch.float32, dev, n_, numel=D)
         _check_dev(best_value, torch.float32, dev, "best_value", (1,))
         if elite_idx is not None:
             _check_dev(elite_idx, torch.int32, dev, "elite_idx", (p.elite_num,))

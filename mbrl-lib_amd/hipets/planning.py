@@ -1,0 +1,389 @@
+"""Drop-in counterparts of mbrl.planning's trajectory-optimisation classes, backed by libhipets.
+
+Same names, constructor arguments and error behaviour as the reference so that the stock Hydra
+configs only swap ``_target_``:
+
+* ``CEMOptimizer``                 <- mbrl/planning/trajectory_opt.py:43-188
+* ``TrajectoryOptimizer``          <- mbrl/planning/trajectory_opt.py:490-572
+* ``TrajectoryOptimizerAgent``     <- mbrl/planning/trajectory_opt.py:575-716
+* ``create_trajectory_optim_agent_for_model`` <- :719-749
+* ``make_eval_fn`` / ``HipTrajectoryEvalFn``  <- the closure at :743-748 around
+  ``ModelEnv.evaluate_action_sequences`` (mbrl/models/model_env.py:145-191)
+
+There is no CPU fallback anywhere in this module: every optimizer needs a gfx950 device.
+"""
+from __future__ import annotations
+
+import importlib
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import HipetsError
+from .engine import Engine
+from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_model_env
+
+_ENGINES: Dict[int, Engine] = {}
+
+
+def get_engine(device) -> Engine:
+    """One Engine per GPU (the reference is single-device, single-threaded)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise HipetsError(f"hipets needs a GPU device, got {device} (there is no CPU fallback)")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ENGINES:
+        _ENGINES[idx] = Engine(torch.device("cuda", idx))
+    return _ENGINES[idx]
+
+
+# ---------------------------------------------------------------------------------------------
+# objective: ModelEnv.evaluate_action_sequences on the fused kernel
+# ---------------------------------------------------------------------------------------------
+class HipTrajectoryEvalFn:
+    """``trajectory_eval_fn(initial_state, action_sequences) -> Tensor[B]`` (mbrl/types.py:15).
+
+    Built from a live ``mbrl.models.ModelEnv`` (weights are re-snapshotted whenever
+    ``ModelTrainer.train`` changed them) or from a ``ModelSpec``.  ``mode='fast'`` draws randomness
+    in-kernel (Philox keyed by ``seed`` and a per-call counter); ``mode='exact'`` reproduces the
+    reference's row->member maps from torch's RNGs, consumed in the reference's order
+    (one ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``).
+    """
+
+    def __init__(self, model, num_particles: int, engine: Optional[Engine] = None, mode: str = "fast",
+                 seed: int = 0, device=None, rng: Optional[torch.Generator] = None):
+        self.num_particles = int(num_particles)
+        self.mode = mode
+        self.seed = int(seed)
+        self.calls = 0
+        self._model_env = None
+        self._version = None
+        if isinstance(model, ModelSpec):
+            spec = model
+            dev = device if device is not None else "cuda:0"
+        else:
+            self._model_env = model
+            spec = spec_from_model_env(model)
+            dev = device if device is not None else getattr(model, "device", "cuda:0")
+            self._version = model_version(model)
+            if rng is None:
+                rng = getattr(model, "_rng", None)
+        self.engine = engine if engine is not None else get_engine(dev)
+        self.device = self.engine.device
+        self.engine.set_model(spec)
+        self.spec = spec
+        self._rng = rng
+        # for multi-GPU: evaluate only candidates [lo, hi) (set by dist.ShardedEvalFn)
+
+    def refresh(self, force: bool = False):
+        """Re-pack weights if the live model changed (mbrl/models/model_trainer.py:288-296)."""
+        if self._model_env is None:
+            return
+        v = model_version(self._model_env)
+        if force or v != self._version:
+            self.spec = spec_from_model_env(self._model_env)
+            self.engine.set_model(self.spec)
+            self._version = v
+
+    def __call__(self, initial_state: np.ndarray, action_sequences: torch.Tensor) -> torch.Tensor:
+        self.refresh()
+        if self.engine.spec is not self.spec:  # engine shared with another eval fn
+            self.engine.set_model(self.spec)
+        a = action_sequences
+        if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        self.calls += 1
+        self.check_batch(a.shape[0])
+        if self.mode == "fast":
+            return self.engine.rollout(a, initial_state, self.num_particles, mode="fast", seed=self.seed,
+                                       stream_id=self.calls)
+        pop, H, _ = a.shape
+        B = pop * self.num_particles
+        perms = eps = None
+        if self.spec.propagation == "fixed_model":
+            perms = torch.randperm(B).to(self.device)  # gaussian_mlp.py:375 at reset
+        if self.spec.propagation == "random_model" or not self.spec.deterministic:
+            p_list, e_list = [], []
+            for _ in range(H):  # reference consumption order, SURVEY.md Appendix A.4
+                if self.spec.propagation == "random_model":
+                    p_list.append(torch.randperm(B))
+                if not self.spec.deterministic:
+                    e_list.append(torch.empty(B, self.spec.out_dim).normal_(0.0, 1.0, generator=self._cpu_rng()))
+            if p_list:
+                perms = torch.stack(p_list).to(self.device)
+            if e_list:
+                eps = torch.stack(e_list).to(self.device)
+        return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", perms=perms, eps=eps)
+
+    def check_batch(self, pop: int):
+        """The reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method and kept in
+        FAST mode too so that switching engines never changes which configurations are accepted."""
+        B, M = pop * self.num_particles, len(self.spec.members)
+        if B % M != 0:
+            raise ValueError(
+                f"GaussianMLP ensemble requires batch size to be a multiple of the "
+                f"number of models. Current batch size is {B} for "
+                f"{M} models."
+            )
+
+    def _cpu_rng(self):
+        if self._rng is not None and self._rng.device.type == "cpu":
+            return self._rng
+        if not hasattr(self, "_own_rng"):
+            self._own_rng = torch.Generator().manual_seed(self.seed)
+        return self._own_rng
+
+
+def make_eval_fn(model, num_particles: int, **kw) -> HipTrajectoryEvalFn:
+    """``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))`` on a stock or a
+    hipets agent (seam 3 of SURVEY.md section 8b)."""
+    return HipTrajectoryEvalFn(model, num_particles, **kw)
+
+
+class _BoundObjective:
+    """``obj_fun(action_sequences)`` with the observation bound (trajectory_opt.py:680-681); carries the
+    engine handle so optimizers can take the fused path."""
+
+    def __init__(self, eval_fn, obs):
+        self.eval_fn = eval_fn
+        self.obs = obs
+
+    def __call__(self, action_sequences):
+        return self.eval_fn(self.obs, action_sequences)
+
+
+def _fused_target(obj_fun) -> Optional[HipTrajectoryEvalFn]:
+    if isinstance(obj_fun, _BoundObjective) and isinstance(obj_fun.eval_fn, HipTrajectoryEvalFn):
+        if obj_fun.eval_fn.mode == "fast":
+            return obj_fun.eval_fn
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizers
+# ---------------------------------------------------------------------------------------------
+class Optimizer:  # trajectory_opt.py:21-40
+    def __init__(self):
+        pass
+
+    def optimize(self, obj_fun, x0=None, callback=None, **kwargs) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class CEMOptimizer(Optimizer):
+    """Cross-Entropy Method with device-side sampling and elite refit (trajectory_opt.py:43-188).
+
+    Works with ANY ``obj_fun`` (generic path: one sample kernel + ``obj_fun`` + one refit kernel per
+    iteration, no host synchronisation of its own); when ``obj_fun`` is a hipets objective in fast mode
+    and no callback is given, the whole optimisation is one ``hipets_plan_cem`` call."""
+
+    def __init__(self, num_iterations: int, elite_ratio: float, population_size: int,
+                 lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]], alpha: float,
+                 device: torch.device, return_mean_elites: bool = False, clipped_normal: bool = False,
+                 seed: Optional[int] = None):
+        super().__init__()
+        self.num_iterations = num_iterations
+        self.elite_ratio = elite_ratio
+        self.population_size = population_size
+        self.elite_num = np.ceil(self.population_size * self.elite_ratio).astype(np.int32)  # :89-91
+        self.device = torch.device(device)
+        self.engine = get_engine(self.device)
+        self.device = self.engine.device
+        self.lower_bound = torch.tensor(lower_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.upper_bound = torch.tensor(upper_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.alpha = alpha
+        self.return_mean_elites = return_mean_elites
+        self._clipped_normal = clipped_normal
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.calls = 0
+        # the reference's CEM is shape-generic (notebooks/cem_rosenbrock_ex.ipynb optimises a [2] vector):
+        # kernels only see the flattened variable; [H, A] bounds keep their meaning for the fused plan path
+        if self.lower_bound.ndim == 2:
+            H, A = self.lower_bound.shape
+        else:
+            H, A = int(self.lower_bound.numel()), 1
+        self._params = Engine.cem_params(population_size, H, A, num_iterations, int(self.elite_num), alpha,
+                                         return_mean_elites, clipped_normal, unbiased_var=True)
+
+    def _init_population_params(self, x0: torch.Tensor):  # :100-108
+        mean = x0.clone()
+        if self._clipped_normal:
+            dispersion = torch.ones_like(mean)
+        else:
+            dispersion = ((self.upper_bound - self.lower_bound) ** 2) / 16
+        return mean, dispersion
+
+    def optimize(self, obj_fun: Callable[[torch.Tensor], torch.Tensor], x0: Optional[torch.Tensor] = None,
+                 callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
+        x0 = x0.to(device=self.device, dtype=torch.float32).contiguous()
+        self.calls += 1
+        fused = _fused_target(obj_fun) if (callback is None and x0.ndim == 2) else None
+        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+            fused.refresh()
+            fused.check_batch(self.population_size)
+            if fused.engine.spec is not fused.spec:
+                fused.engine.set_model(fused.spec)
+            return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
+                                        fused.num_particles, seed=self.seed ^ fused.seed, plan_id=self.calls)
+        p = self._params
+        mu, dispersion = self._init_population_params(x0)
+        mu, dispersion = mu.contiguous(), dispersion.contiguous()
+        best_solution = torch.zeros_like(mu)
+        best_value = torch.full((1,), -float("inf"), device=self.device, dtype=torch.float32)
+        population = torch.empty((self.population_size,) + tuple(x0.shape), device=self.device, dtype=torch.float32)
+        noise = kwargs.get("noise")  # optional injected z per iteration (parity tests)
+        for i in range(self.num_iterations):
+            z = None if noise is None else noise[i].to(self.device, torch.float32).contiguous()
+            self.engine.cem_sample(p, mu, dispersion, self.lower_bound, self.upper_bound, population, z=z,
+                                   seed=self.seed, stream_id=self.calls * self.num_iterations + i)
+            values = obj_fun(population)
+            if callback is not None:
+                callback(population, values, i)
+            if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
+                values = values.to(device=self.device, dtype=torch.float32).contiguous()
+            self.engine.cem_refit(p, values, population, mu, dispersion, best_value, best_solution)
+        return mu if self.return_mean_elites else best_solution
+
+
+# ---------------------------------------------------------------------------------------------
+# TrajectoryOptimizer / Agent
+# ---------------------------------------------------------------------------------------------
+_TARGET_ALIASES = {
+    # stock targets are redirected to the fused implementations when an agent of this module builds them
+    "mbrl.planning.CEMOptimizer": "hipets.planning.CEMOptimizer",
+    "mbrl.planning.trajectory_opt.CEMOptimizer": "hipets.planning.CEMOptimizer",
+}
+
+
+def _cfg_get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except (KeyError, TypeError, AttributeError):
+        return getattr(cfg, key, default)
+
+
+def _instantiate(cfg, **overrides):
+    """hydra.utils.instantiate when hydra is present, else a minimal ``_target_`` resolver
+    (object construction only; the reference does exactly this at trajectory_opt.py:527,741)."""
+    kwargs = {k: cfg[k] for k in cfg.keys()}
+    kwargs.update(overrides)
+    target = kwargs.pop("_target_")
+    target = _TARGET_ALIASES.get(target, target)
+    kwargs = {k: v for k, v in kwargs.items() if not (isinstance(v, str) and v == "???")}
+    mod, _, name = target.rpartition(".")
+    return getattr(importlib.import_module(mod), name)(**kwargs)
+
+
+class TrajectoryOptimizer:
+    """trajectory_opt.py:490-572: tiles the action bounds over the horizon, instantiates the optimizer,
+    warm-starts each call from the previous solution shifted by ``replan_freq``."""
+
+    def __init__(self, optimizer_cfg, action_lb: np.ndarray, action_ub: np.ndarray, planning_horizon: int,
+                 replan_freq: int = 1, keep_last_solution: bool = True):
+        lower = np.tile(action_lb, (planning_horizon, 1)).tolist()  # :525
+        upper = np.tile(action_ub, (planning_horizon, 1)).tolist()  # :526
+        self.optimizer: Optimizer = _instantiate(optimizer_cfg, lower_bound=lower, upper_bound=upper)  # :527
+        device = self.optimizer.device
+        self.initial_solution = ((torch.tensor(action_lb) + torch.tensor(action_ub)) / 2).float().to(device)
+        self.initial_solution = self.initial_solution.repeat((planning_horizon, 1))
+        self.previous_solution = self.initial_solution.clone()
+        self.replan_freq = replan_freq
+        self.keep_last_solution = keep_last_solution
+        self.horizon = planning_horizon
+
+    def optimize(self, trajectory_eval_fn: Callable[[torch.Tensor], torch.Tensor],
+                 callback: Optional[Callable] = None) -> np.ndarray:
+        best_solution = self.optimizer.optimize(trajectory_eval_fn, x0=self.previous_solution, callback=callback)
+        if self.keep_last_solution:  # :563-567
+            self.previous_solution = best_solution.roll(-self.replan_freq, dims=0)
+            self.previous_solution[-self.replan_freq:] = self.initial_solution[0]
+        return best_solution.cpu().numpy()  # the one device->host sync of a plan (:568)
+
+    def reset(self):
+        self.previous_solution = self.initial_solution.clone()
+
+
+class Agent:  # mbrl/planning/core.py:18-49
+    def act(self, obs: np.ndarray, **_kwargs) -> np.ndarray:
+        raise NotImplementedError
+
+    def plan(self, obs: np.ndarray, **_kwargs) -> np.ndarray:
+        return self.act(obs, **_kwargs)
+
+    def reset(self):
+        pass
+
+
+class TrajectoryOptimizerAgent(Agent):
+    """trajectory_opt.py:575-716 with the same public methods (``set_trajectory_eval_fn``, ``reset``,
+    ``act``, ``plan``) and the same RuntimeError when no objective was set (:673-676)."""
+
+    def __init__(self, optimizer_cfg, action_lb: Sequence[float], action_ub: Sequence[float], planning_horizon: int = 1,
+                 replan_freq: int = 1, verbose: bool = False, keep_last_solution: bool = True):
+        self.optimizer = TrajectoryOptimizer(optimizer_cfg, np.array(action_lb), np.array(action_ub),
+                                             planning_horizon=planning_horizon, replan_freq=replan_freq,
+                                             keep_last_solution=keep_last_solution)
+        self.optimizer_args = {"optimizer_cfg": optimizer_cfg, "action_lb": np.array(action_lb),
+                               "action_ub": np.array(action_ub)}
+        self.trajectory_eval_fn = None
+        self.actions_to_use: List[np.ndarray] = []
+        self.replan_freq = replan_freq
+        self.verbose = verbose
+
+    def set_trajectory_eval_fn(self, trajectory_eval_fn):
+        self.trajectory_eval_fn = trajectory_eval_fn
+
+    def reset(self, planning_horizon: Optional[int] = None):
+        if planning_horizon:  # :644-651
+            self.optimizer = TrajectoryOptimizer(self.optimizer_args["optimizer_cfg"], self.optimizer_args["action_lb"],
+                                                 self.optimizer_args["action_ub"], planning_horizon=planning_horizon,
+                                                 replan_freq=self.replan_freq)
+        self.optimizer.reset()
+
+    def _require_eval_fn(self):
+        if self.trajectory_eval_fn is None:
+            raise RuntimeError("Please call `set_trajectory_eval_fn()` before using TrajectoryOptimizerAgent")
+
+    def act(self, obs: np.ndarray, optimizer_callback: Optional[Callable] = None, **_kwargs) -> np.ndarray:
+        self._require_eval_fn()
+        plan_time = 0.0
+        if not self.actions_to_use:  # re-plan is necessary (:678)
+            start_time = time.time()
+            plan = self.optimizer.optimize(_BoundObjective(self.trajectory_eval_fn, obs), callback=optimizer_callback)
+            plan_time = time.time() - start_time
+            self.actions_to_use.extend([a for a in plan[: self.replan_freq]])
+        action = self.actions_to_use.pop(0)
+        if self.verbose:
+            print(f"Planning time: {plan_time:.3f}")
+        return action
+
+    def plan(self, obs: np.ndarray, **_kwargs) -> np.ndarray:
+        self._require_eval_fn()
+        return self.optimizer.optimize(_BoundObjective(self.trajectory_eval_fn, obs))
+
+
+def complete_agent_cfg(env, agent_cfg):
+    """The subset of mbrl/planning/core.py:71-123 a trajectory-optimizer agent config needs: fill
+    ``action_lb`` / ``action_ub`` placeholders ("???" or missing) from the action space."""
+    def missing(key):
+        try:
+            v = agent_cfg[key]
+        except (KeyError, AttributeError):
+            return key in getattr(agent_cfg, "keys", lambda: [])()
+        return isinstance(v, str) and v == "???"
+
+    if missing("action_lb"):
+        agent_cfg["action_lb"] = env.action_space.low.tolist()
+    if missing("action_ub"):
+        agent_cfg["action_ub"] = env.action_space.high.tolist()
+    return agent_cfg
+
+
+def create_trajectory_optim_agent_for_model(model_env, agent_cfg, num_particles: int = 1, **eval_kw):
+    """trajectory_opt.py:719-749, with the objective bound to the fused kernel."""
+    complete_agent_cfg(model_env, agent_cfg)
+    agent = _instantiate(agent_cfg)
+    agent.set_trajectory_eval_fn(make_eval_fn(model_env, num_particles, **eval_kw))
+    return agent

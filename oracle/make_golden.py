@@ -1,0 +1,154 @@
+"""TEST INFRASTRUCTURE ONLY: generate tests/golden/*.npz by running the UNMODIFIED reference
+(/root/reference, through oracle/ref_stubs) with seeded RNG and recording the random draws it
+consumed (in its consumption order) next to its outputs.
+
+    python -m oracle.make_golden            # from the repo root, in the build container
+
+The fixtures pin the oracle (and the HIP engine) on machines where the reference is absent.
+While generating, the script also asserts oracle == reference bitwise for every case.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pets_oracle as po  # noqa: E402
+from oracle.golden_io import save_case  # noqa: E402
+from oracle.ref_bridge import build_reference_model_env, import_reference  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+ROLLOUT_CASES = {
+    # name: (obs, act, model kwargs, pop, P, H)
+    "ts1_halfcheetah": (17, 6, dict(ensemble_size=5, hid=64, seed=10, no_delta_list=[0]), 30, 5, 5),
+    "ts1_cartpole_term": (4, 1, dict(ensemble_size=3, hid=200, seed=11, reward="cartpole", termination="cartpole"), 21, 5, 15),
+    "tsinf_elite_humanoid": (45, 17, dict(ensemble_size=7, hid=32, seed=12, elite=[0, 2, 3, 5, 6], propagation="fixed_model",
+                                            termination="humanoid"), 10, 5, 4),
+    "expectation_learned_rew": (18, 6, dict(ensemble_size=4, hid=48, seed=13, propagation="expectation", learned_rewards=True,
+                                            reward=None, obs_process="halfcheetah", normalizer="f32", activation="relu"), 12, 3, 6),
+    "deterministic_cartpole_pets": (4, 1, dict(ensemble_size=2, hid=40, seed=14, deterministic=True, obs_process="cartpole_pets",
+                                               reward="cartpole_pets", normalizer="none", activation="leaky_relu",
+                                               target_is_delta=False), 16, 4, 7),
+    "ts1_hopper_tanh": (11, 3, dict(ensemble_size=5, hid=24, num_layers=2, seed=15, activation="tanh", termination="hopper",
+                                    reward="halfcheetah"), 25, 4, 8),
+}
+
+
+def gen_rollout(name, obs, act, mkw, pop, P, H):
+    om = po.make_synthetic_model(obs, act, **mkw)
+    g = torch.Generator().manual_seed(100 + len(name))
+    # termination cases: start near the boundary so that some particles terminate mid-horizon
+    scale = 0.1
+    s0 = (np.random.default_rng(5).standard_normal(obs) * scale).astype(np.float32)
+    if om.termination == "humanoid":
+        s0[0] = 1.05
+    if om.termination == "hopper":
+        s0[0] = 0.75
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    B = pop * P
+    gen = torch.Generator().manual_seed(7)
+    me, dm, model = build_reference_model_env(om, obs, act, generator=gen)
+    torch.manual_seed(1234)
+    ref = me.evaluate_action_sequences(actions, s0, P)
+    # replay the reference's RNG consumption to record the draws (Appendix A.4)
+    torch.manual_seed(1234)
+    gen2 = torch.Generator().manual_seed(7)
+    arrays = dict(actions=actions, s0=s0, returns=ref)
+    out = om.out_size
+    perms = None
+    if om.propagation == "fixed_model":
+        perms = torch.randperm(B)  # reset: sample_propagation_indices ignores the generator (gaussian_mlp.py:375)
+    plist, elist = [], []
+    for _ in range(H):
+        if om.propagation == "random_model":
+            plist.append(torch.randperm(B))
+        if not om.deterministic:
+            elist.append(torch.empty(B, out).normal_(0, 1, generator=gen2))
+    if plist:
+        perms = torch.stack(plist)
+    eps = torch.stack(elist) if elist else None
+    trace = {}
+    mine = po.rollout(om, actions, s0, P, perms=perms, eps=eps, trace=trace)
+    assert torch.equal(ref, mine), f"{name}: oracle != reference (max diff {(ref - mine).abs().max()})"
+    if perms is not None:
+        arrays["perms"] = perms
+    if eps is not None:
+        arrays["eps"] = eps
+    arrays["next_obs_step0"] = trace["next_obs"][0]
+    arrays["rewards_step0"] = trace["rewards"][0]
+    n_term = int(torch.stack(trace["dones"]).any(0).sum())
+    save_case(os.path.join(OUT, f"rollout_{name}.npz"), om, dict(kind="rollout", obs_dim=obs, act_dim=act, pop=pop, P=P, H=H,
+                                                                  rows_terminated=n_term), arrays)
+    print(f"rollout_{name}: B={B} returns[{ref.min():.3f},{ref.max():.3f}] terminated rows={n_term}  oracle==reference bitwise")
+
+
+def gen_cem(name, clipped, return_mean, pop=40, H=6, A=3, iters=4, ratio=0.15, alpha=0.1):
+    mbrl = import_reference()
+    torch.manual_seed(77)
+    lb = [[-1.0, -0.5, -2.0][:A]] * H
+    ub = [[1.0, 1.5, 0.5][:A]] * H
+    target = torch.linspace(-0.4, 0.4, H * A).view(H, A)
+
+    def obj(x):  # smooth objective with a few NaNs to pin the NaN -> -1e-10 rule
+        v = -((x - target) ** 2).sum(dim=(1, 2))
+        v = v.clone()
+        v[3] = float("nan")
+        return v
+
+    opt = mbrl.planning.CEMOptimizer(iters, ratio, pop, lb, ub, alpha, "cpu", return_mean_elites=return_mean,
+                                     clipped_normal=clipped)
+    x0 = torch.zeros(H, A)
+    pops, vals = [], []
+
+    def cb(population, values, i):
+        pops.append(population.clone())
+        vals.append(values.clone())
+
+    torch.manual_seed(5)
+    ref = opt.optimize(obj, x0=x0, callback=cb)
+    # recover z of every iteration by replaying the same RNG stream
+    torch.manual_seed(5)
+    zs = []
+    for i in range(iters):
+        if clipped:
+            zs.append(torch.randn(pop, H, A))
+        else:
+            zs.append(po.truncated_normal_(torch.zeros(pop, H, A)))
+    rec = []
+    mine = po.cem_optimize(obj, x0, torch.tensor(lb), torch.tensor(ub), iters, ratio, pop, alpha, return_mean_elites=return_mean,
+                           clipped_normal=clipped, noise=zs, record=rec)
+    assert torch.equal(ref, mine), f"{name}: oracle CEM != reference"
+    for i in range(iters):
+        assert torch.equal(rec[i]["population"], pops[i])
+    arrays = dict(z=torch.stack(zs), lower=torch.tensor(lb), upper=torch.tensor(ub), x0=x0, target=target, result=ref,
+                  populations=torch.stack(pops), values=torch.stack([r["values"] for r in rec]),
+                  mus=torch.stack([r["mu"] for r in rec]), disps=torch.stack([r["disp"] for r in rec]),
+                  elite_idx=torch.stack([r["elite_idx"] for r in rec]))
+    meta = dict(kind="cem", pop=pop, H=H, A=A, iters=iters, elite_ratio=ratio, alpha=alpha, clipped=clipped,
+                return_mean=return_mean, nan_index=3, n_layers=0)
+    d = {"x_" + k: v.numpy() for k, v in arrays.items()}
+    import json
+
+    d["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez(os.path.join(OUT, f"cem_{name}.npz"), **d)
+    print(f"cem_{name}: oracle==reference bitwise; result[0]={ref[0].tolist()}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    for name, (obs, act, mkw, pop, P, H) in ROLLOUT_CASES.items():
+        gen_rollout(name, obs, act, mkw, pop, P, H)
+    gen_cem("truncated_mean", clipped=False, return_mean=True)
+    gen_cem("truncated_best", clipped=False, return_mean=False)
+    gen_cem("clipped_mean", clipped=True, return_mean=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -229,6 +229,12 @@ def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tenso
     """
     B = x.shape[0]
     M = len(m.active_members)
+    if member_of_row is None and B % M != 0:  # gaussian_mlp.py:195-200 (checked for EVERY propagation method)
+        raise ValueError(
+            f"GaussianMLP ensemble requires batch size to be a multiple of the "
+            f"number of models. Current batch size is {B} for "
+            f"{M} models."
+        )
     if m.propagation in ("random_model", "fixed_model"):
         if member_of_row is not None:
             mean = torch.empty(B, m.weights[-1].shape[-1] // (1 if m.deterministic else 2))
@@ -243,12 +249,6 @@ def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tenso
                 if lv_s is not None:
                     logvar[rows] = lv_s[0]
             return mean, logvar
-        if B % M != 0:  # gaussian_mlp.py:195-200
-            raise ValueError(
-                f"GaussianMLP ensemble requires batch size to be a multiple of the "
-                f"number of models. Current batch size is {B} for "
-                f"{M} models."
-            )
         shuffled = x.unsqueeze(0)[:, perm, ...].view(M, B // M, -1)  # :164-166
         mean, logvar = _members_forward(m, shuffled)
         mean = mean.reshape(B, -1)
@@ -300,11 +300,13 @@ def rollout(
     out = m.weights[-1].shape[-1] // (1 if m.deterministic else 2)
     fixed_perm = None
     if m.propagation == "fixed_model" and members is None:
-        # model.py:404-407 -> gaussian_mlp.py:363-375 (randperm with the ModelEnv generator)
+        # model.py:404-407 -> gaussian_mlp.py:363-375: randperm from the GLOBAL rng (the generator is
+        # deliberately ignored there, see the comment at gaussian_mlp.py:374)
         if perms is not None:
             fixed_perm = perms if perms.ndim == 1 else perms[0]
         else:
-            fixed_perm = torch.randperm(B, generator=generator)
+            assert global_rng
+            fixed_perm = torch.randperm(B)
     rew_fn = REWARD_FNS[m.reward] if m.reward is not None else None
     term_fn = TERMINATION_FNS[m.termination]
     for t in range(H):

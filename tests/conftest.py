@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "mbrl-lib_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def to_spec(om, obs_dim, act_dim):
+    """OracleModel (test infra) -> hipets.ModelSpec (product).  The product never sees the oracle."""
+    import hipets
+
+    return hipets.ModelSpec(
+        weights=om.weights, biases=om.biases, obs_dim=obs_dim, act_dim=act_dim, min_logvar=om.min_logvar,
+        max_logvar=om.max_logvar, elite_models=om.elite_models, activation=om.activation, propagation=om.propagation,
+        deterministic=om.deterministic, norm_mean=om.norm_mean, norm_std=om.norm_std, target_is_delta=om.target_is_delta,
+        no_delta_list=om.no_delta_list, learned_rewards=om.learned_rewards, obs_process=om.obs_process, reward=om.reward,
+        termination=om.termination,
+    )
+
+
+@pytest.fixture(scope="session")
+def engine():
+    import torch
+
+    import hipets
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return hipets.get_engine("cuda:0")

@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/hipets.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "hipets.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hipets_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    fns = header_functions()
+    for must in ("hipets_create", "hipets_destroy", "hipets_set_model", "hipets_rollout", "hipets_cem_sample",
+                 "hipets_cem_refit", "hipets_plan_cem", "hipets_last_error", "hipets_abi_version"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    from hipets import _lib
+
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), f"libhipets.so does not export {name}"
+    assert sorted(_lib.SYMBOLS) == header_functions(), "ctypes binding and header disagree"
+    assert lib.hipets_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header_field_order():
+    """Field names of the ctypes structs follow the header's declaration order."""
+    from hipets import _lib
+
+    src = open(HEADER).read()
+
+    def fields(struct_name):
+        body = re.search(r"typedef struct \{([^{}]*)\} " + struct_name + ";", src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [re.findall(r"([a-z_0-9]+)\s*$", decl.strip())[0] for decl in body.split(";") if decl.strip()]
+
+    assert fields("hipets_model_desc") == [f[0] for f in _lib.ModelDesc._fields_]
+    assert fields("hipets_rollout_opts") == [f[0] for f in _lib.RolloutOpts._fields_]
+    assert fields("hipets_cem_params") == [f[0] for f in _lib.CemParams._fields_]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product refuses to run instead of computing on the CPU."""
+    import hipets
+    from hipets import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.hipets_create(0, ctypes.byref(h)) != 0
+    assert b"no CPU fallback" in lib.hipets_last_error()
+    with pytest.raises(hipets.HipetsError):
+        hipets.get_engine("cpu")
+    with pytest.raises(hipets.HipetsError):
+        hipets.CEMOptimizer(2, 0.1, 10, [[-1.0]], [[1.0]], 0.1, "cpu")
+
+
+def test_product_never_imports_oracle():
+    """The parity claim is void if the product path routes through the oracle: grep the package."""
+    pkg = os.path.join(ROOT, "mbrl-lib_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pets_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,228 @@
+"""Optimizer kernels and the host-side drop-in classes on the GPU, against the reference's golden vectors
+(tests/golden/cem_*.npz) and the oracle.  Tolerances: T3 elite sets equal; T4 refit mu/var and
+returned plan atol 1e-4 (measured ~1e-7)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hipets
+from conftest import GOLDEN, to_spec
+from oracle import pets_oracle as po
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CEM_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cem_*.npz")))
+
+
+def load_cem(path):
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return meta, {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x_")}
+
+
+@pytest.mark.parametrize("path", CEM_FILES, ids=lambda p: os.path.basename(p)[4:-4])
+def test_cem_kernels_match_reference_iteration_by_iteration(engine, path):
+    meta, a = load_cem(path)
+    pop, H, A, iters = meta["pop"], meta["H"], meta["A"], meta["iters"]
+    K = po.elite_count(pop, meta["elite_ratio"])
+    p = engine.cem_params(pop, H, A, iters, K, meta["alpha"], meta["return_mean"], meta["clipped"])
+    lower, upper = a["lower"].to(DEV), a["upper"].to(DEV)
+    mu = a["x0"].clone().to(DEV)
+    disp = (torch.ones(H, A) if meta["clipped"] else ((a["upper"] - a["lower"]) ** 2) / 16).to(DEV)
+    best_v = torch.full((1,), -float("inf"), device=DEV)
+    best = torch.zeros(H, A, device=DEV)
+    population = torch.empty(pop, H, A, device=DEV)
+    eidx = torch.empty(K, dtype=torch.int32, device=DEV)
+    for i in range(iters):
+        engine.cem_sample(p, mu, disp, lower, upper, population, z=a["z"][i].to(DEV))
+        assert torch.allclose(population.cpu(), a["populations"][i], rtol=0, atol=1e-6)
+        raw = a["values"][i].clone()
+        raw[meta["nan_index"]] = float("nan")
+        values = raw.to(DEV)
+        engine.cem_refit(p, values, population, mu, disp, best_v, best, eidx)
+        assert values[meta["nan_index"]].item() == pytest.approx(-1e-10)  # Appendix B1, in place like the reference
+        assert set(eidx.cpu().tolist()) == set(a["elite_idx"][i].tolist())  # T3
+        assert eidx[0].item() == a["elite_idx"][i][0].item()
+        assert torch.allclose(mu.cpu(), a["mus"][i], rtol=0, atol=1e-5)  # T4
+        assert torch.allclose(disp.cpu(), a["disps"][i], rtol=1e-5, atol=1e-6)
+    result = mu if meta["return_mean"] else best
+    assert torch.allclose(result.cpu(), a["result"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("path", CEM_FILES, ids=lambda p: os.path.basename(p)[4:-4])
+def test_cem_optimizer_class_generic_path(path):
+    """hipets.CEMOptimizer with an arbitrary Python objective (the diagnostics/control_env.py use of the seam)."""
+    meta, a = load_cem(path)
+    target = a["target"].to(DEV)
+
+    def obj(x):
+        v = -((x - target) ** 2).sum(dim=(1, 2)).clone()
+        v[meta["nan_index"]] = float("nan")
+        return v
+
+    seen = []
+    opt = hipets.CEMOptimizer(meta["iters"], meta["elite_ratio"], meta["pop"], a["lower"].tolist(), a["upper"].tolist(),
+                              meta["alpha"], DEV, return_mean_elites=meta["return_mean"], clipped_normal=meta["clipped"])
+    out = opt.optimize(obj, x0=a["x0"], callback=lambda pop_, v, i: seen.append((pop_.shape, i)), noise=list(a["z"]))
+    assert out.device.type == "cuda" and tuple(out.shape) == (meta["H"], meta["A"])
+    assert torch.allclose(out.cpu(), a["result"], rtol=0, atol=1e-5)
+    assert [s[1] for s in seen] == list(range(meta["iters"]))
+
+
+def test_cem_rosenbrock_known_answer():
+    """notebooks/cem_rosenbrock_ex.ipynb cell 2: CEMOptimizer(5, 0.01, 1000, [-2,-2], [2,2], 0.1) -> ~[1, 1]."""
+    def rosenbrock(x, a=1.0, b=100.0):
+        return -((a - x[:, 0]) ** 2 + b * (x[:, 1] - x[:, 0] ** 2) ** 2)
+
+    opt = hipets.CEMOptimizer(5, 0.01, 1000, [-2.0, -2.0], [2.0, 2.0], 0.1, torch.device(DEV), seed=0)
+    best = opt.optimize(rosenbrock, torch.zeros(2))
+    assert tuple(best.shape) == (2,)
+    assert torch.allclose(best.cpu(), torch.ones(2), atol=0.05)
+    assert rosenbrock(best.view(1, 2)).item() > -1e-2
+
+
+def test_philox_truncated_normal_sampler(engine):
+    """tests/core/test_common_utils.py:419-423 (support) + the law: N(0,1) truncated to [-2,2] has var 0.7737."""
+    pop, H, A = 4096, 10, 5
+    p = engine.cem_params(pop, H, A, 1, 10, 0.1)
+    z = torch.empty(pop, H, A, device=DEV)
+    one, zero = torch.ones(H, A, device=DEV), torch.zeros(H, A, device=DEV)
+    # lower/upper far away, dispersion 1 => population == z
+    engine.cem_sample(p, zero, one, -1e3 * one, 1e3 * one, z, seed=3, stream_id=1)
+    v = z.double().cpu().flatten()
+    assert (v > -2).all() and (v < 2).all()
+    n = v.numel()
+    assert abs(v.mean()) < 5 * np.sqrt(0.7737 / n)
+    assert abs(v.var() - 0.77374) < 0.01
+    z2 = torch.empty_like(z)
+    engine.cem_sample(p, zero, one, -1e3 * one, 1e3 * one, z2, seed=3, stream_id=1)
+    assert torch.equal(z, z2)
+    engine.cem_sample(p, zero, one, -1e3 * one, 1e3 * one, z2, seed=3, stream_id=2)
+    assert not torch.equal(z, z2)
+    # bound-aware variance (trajectory_opt.py:122-127): near a bound samples stay inside it
+    mu = 0.9 * one
+    engine.cem_sample(p, mu, one, -one, one, z, seed=4, stream_id=0)
+    assert (z <= 1.0).all() and (z >= -1.0).all()
+
+
+def _model_env_like(om, obs, act):
+    class Space:
+        def __init__(self, n):
+            self.shape = (n,)
+            self.low, self.high = -np.ones(n, np.float32), np.ones(n, np.float32)
+
+    class ME:
+        observation_space, action_space = Space(obs), Space(act)
+
+    return ME()
+
+
+def test_agent_act_fused_path_is_deterministic_and_improves_return(engine):
+    """TrajectoryOptimizerAgent.act (trajectory_opt.py:655-694) end to end on the fused CEM plan."""
+    obs, act, H, P, pop = 17, 6, 12, 10, 200
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=64, seed=3)
+    om.max_logvar = torch.full_like(om.max_logvar, -8.0)  # low-noise model: returns are dominated by the actions
+    spec = to_spec(om, obs, act)
+    cfg = dict(_target_="hipets.CEMOptimizer", num_iterations=4, elite_ratio=0.1, population_size=pop, alpha=0.1,
+               device=DEV, lower_bound="???", upper_bound="???", return_mean_elites=True, seed=11)
+
+    def make_agent():
+        agent = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H)
+        with pytest.raises(RuntimeError, match="set_trajectory_eval_fn"):  # trajectory_opt.py:673-676
+            agent.act(np.zeros(obs))
+        agent.set_trajectory_eval_fn(hipets.make_eval_fn(spec, P, engine=engine, seed=5))
+        return agent
+
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+    a1, a2 = make_agent(), make_agent()
+    act1, act2 = a1.act(s0), a2.act(s0)
+    assert act1.shape == (act,) and act1.dtype == np.float32
+    assert np.array_equal(act1, act2)  # same seeds -> identical action selection
+    plan = a1.plan(s0)
+    assert plan.shape == (H, act) and (np.abs(plan) <= 1).all()
+    # the optimised plan beats random action sequences under the model (scored by the oracle with independent
+    # randomness; the control cost makes random plans score about -2.5 here and a converged plan about 0)
+    g = torch.Generator().manual_seed(0)
+    cands = torch.cat([torch.from_numpy(plan)[None], torch.rand(9, H, act, generator=g) * 2 - 1])
+    B = 10 * 50
+    perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+    eps = torch.randn(H, B, obs, generator=g)
+    r = po.rollout(om, cands, s0, 50, perms=perms, eps=eps)
+    assert r[0] > r[1:].max() + 1.0
+    # warm start: previous solution is the plan shifted by replan_freq with (lb+ub)/2 refill (:563-567)
+    prev = a1.optimizer.previous_solution.cpu().numpy()
+    assert np.allclose(prev[:-1], plan[1:]) and np.allclose(prev[-1], 0.0)
+    a1.reset()
+    assert torch.equal(a1.optimizer.previous_solution, a1.optimizer.initial_solution)
+
+
+def test_generic_and_fused_paths_agree_statistically(engine):
+    """The fused hipets_plan_cem and the per-iteration generic path are the same algorithm: both produce plans of
+    the same quality (scored by the oracle), far better than random action sequences."""
+    obs, act, H, P, pop = 17, 6, 8, 10, 300
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=32, seed=4)
+    om.max_logvar = torch.full_like(om.max_logvar, -8.0)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=1)
+    from hipets.planning import _BoundObjective
+
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    opt = hipets.CEMOptimizer(5, 0.1, pop, lb, ub, 0.1, DEV, return_mean_elites=True, seed=2)
+    s0 = np.zeros(obs, np.float32)
+    fused = opt.optimize(_BoundObjective(fn, s0), x0=torch.zeros(H, act))
+    generic = opt.optimize(_BoundObjective(fn, s0), x0=torch.zeros(H, act), force_generic=True)
+    assert torch.isfinite(fused).all() and torch.isfinite(generic).all()
+    g = torch.Generator().manual_seed(0)
+    cands = torch.cat([fused.cpu()[None], generic.cpu()[None], torch.rand(8, H, act, generator=g) * 2 - 1])
+    B = 10 * 50
+    perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+    eps = torch.randn(H, B, obs, generator=g)
+    r = po.rollout(om, cands, s0, 50, perms=perms, eps=eps)
+    assert r[0] > r[2:].max() + 0.5 and r[1] > r[2:].max() + 0.5
+    assert abs(r[0] - r[1]) < 0.3
+
+
+def test_eval_fn_exact_mode_replays_reference_rng_order(engine):
+    """mode='exact' consumes torch's RNGs in the reference's order, so with the same
+    seeds it reproduces ModelEnv.evaluate_action_sequences (here: the oracle drawing in that same order)."""
+    obs, act, pop, P, H = 17, 6, 20, 5, 6
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=6)
+    g = torch.Generator().manual_seed(1)
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = np.zeros(obs, np.float32)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, mode="exact", rng=torch.Generator().manual_seed(3))
+    torch.manual_seed(8)
+    out = fn(s0, actions.to(DEV))
+    torch.manual_seed(8)
+    ref = po.rollout(om, actions, s0, P, global_rng=True, generator=torch.Generator().manual_seed(3))
+    assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-4)
+    fn3 = hipets.make_eval_fn(to_spec(om, obs, act), 3, engine=engine, mode="fast")
+    with pytest.raises(ValueError, match="multiple of the number of models"):  # 4 x 3 rows, 5 members
+        fn3(s0, actions[:4].to(DEV))
+
+
+def test_create_agent_for_model_env_and_resnapshot(engine):
+    """create_trajectory_optim_agent_for_model (trajectory_opt.py:719-749) on a duck-typed ModelEnv; the
+    objective re-packs weights when the live parameters change."""
+    from test_host_logic import _FakeModelEnv
+
+    me = _FakeModelEnv()
+    me.device = DEV
+    for layer in me.dynamics_model.model.hidden_layers:
+        torch.nn.init.normal_(layer[0].weight, std=0.3)
+    cfg = dict(_target_="hipets.TrajectoryOptimizerAgent", action_lb="???", action_ub="???", planning_horizon=4,
+               optimizer_cfg=dict(_target_="mbrl.planning.CEMOptimizer", num_iterations=2, elite_ratio=0.2, population_size=30,
+                                  alpha=0.1, device=DEV, lower_bound="???", upper_bound="???", return_mean_elites=True))
+    agent = hipets.create_trajectory_optim_agent_for_model(me, cfg, num_particles=3, engine=engine)
+    assert isinstance(agent.optimizer.optimizer, hipets.CEMOptimizer)  # stock target redirected to the fused class
+    a = agent.act(np.zeros(5, np.float32))
+    assert a.shape == (2,)
+    fn = agent.trajectory_eval_fn
+    v0 = fn._version
+    with torch.no_grad():
+        me.dynamics_model.model.mean_and_logvar.weight.add_(0.1)
+    agent.act(np.zeros(5, np.float32))
+    assert fn._version != v0

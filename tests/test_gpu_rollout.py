@@ -1,0 +1,222 @@
+"""Parity tests proper: the HIP rollout (through the C-ABI) against the reference's golden vectors and
+against the oracle on seeded inputs.  Tolerances (SURVEY.md section 8c tiers), written here:
+  T1  one rollout step, injected perm/eps: next_obs, reward    rtol 1e-5, atol 2e-6
+  T2  H-step returns [pop]                                     |err| <= 1e-4 * max(1, |v|)
+f32 MFMA accumulation is an fmaf chain in a different k order than ATen's bmm, hence not bitwise."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, to_spec
+from oracle import pets_oracle as po
+from oracle.golden_io import load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def assert_returns_close(out, ref):
+    out, ref = out.detach().cpu(), ref.detach().cpu()
+    tol = 1e-4 * torch.clamp(ref.abs(), min=1.0)
+    bad = (out - ref).abs() > tol
+    assert not bad.any(), f"max err {(out - ref).abs().max():.3e} at {int(bad.nonzero()[0])}"
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[8:-4])
+@pytest.mark.parametrize("R", [0, 1, 3])
+def test_golden_reference_vectors_exact_mode(engine, path, R):
+    om, meta, a = load_case(path)
+    engine.set_model(to_spec(om, meta["obs_dim"], meta["act_dim"]))
+    H, B = meta["H"], meta["pop"] * meta["P"]
+    tno = torch.zeros(H, B, meta["obs_dim"], device=DEV)
+    trw = torch.zeros(H, B, device=DEV)
+    perms = a["perms"].to(DEV) if "perms" in a else None
+    eps = a["eps"].to(DEV) if "eps" in a else None
+    out = engine.rollout(a["actions"].to(DEV), a["s0"].numpy(), meta["P"], mode="exact", perms=perms, eps=eps,
+                         trace_next_obs=tno, trace_rewards=trw, rows_per_group=R)
+    assert torch.allclose(tno[0].cpu(), a["next_obs_step0"], rtol=1e-5, atol=2e-6)  # T1
+    assert torch.allclose(trw[0].cpu(), a["rewards_step0"].flatten(), rtol=1e-5, atol=2e-6)
+    assert_returns_close(out, a["returns"])  # T2
+
+
+def _random_case(obs, act, pop, P, H, seed=0, **mkw):
+    om = po.make_synthetic_model(obs, act, seed=seed, **mkw)
+    g = torch.Generator().manual_seed(seed + 1)
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = (np.random.default_rng(seed).standard_normal(obs) * 0.1).astype(np.float32)
+    B = pop * P
+    if om.propagation == "random_model":
+        perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+    elif om.propagation == "fixed_model":
+        perms = torch.randperm(B, generator=g)
+    else:
+        perms = None
+    eps = None if om.deterministic else torch.randn(H, B, om.out_size, generator=g)
+    return om, actions, s0, perms, eps
+
+
+SIZES = [
+    # obs, act, pop, P, H, model kwargs  (ragged tiles, tiny batches, wide/narrow nets, all propagation modes)
+    (17, 6, 500, 20, 30, dict(ensemble_size=5, hid=200)),  # cfg2 at BASELINE.json's full size
+    (4, 1, 100, 5, 15, dict(ensemble_size=5, hid=200, reward="cartpole", termination="cartpole")),  # cfg1
+    (45, 17, 35, 20, 6, dict(ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")),  # cfg4 shape
+    (17, 6, 1, 5, 3, dict(ensemble_size=5, hid=200)),  # single candidate
+    (17, 6, 7, 5, 4, dict(ensemble_size=5, hid=33)),  # odd hidden width
+    (17, 6, 48, 10, 3, dict(ensemble_size=2, hid=256, num_layers=2)),
+    (17, 6, 30, 4, 5, dict(ensemble_size=3, hid=512, num_layers=3, propagation="fixed_model")),
+    (6, 2, 10, 3, 5, dict(ensemble_size=5, hid=16, propagation="expectation", normalizer="f32")),
+    (376, 17, 10, 5, 2, dict(ensemble_size=5, hid=200, termination="humanoid")),  # cfg4' input width 393
+]
+
+
+@pytest.mark.parametrize("case", SIZES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_exact_mode_matches_oracle(engine, case):
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, perms, eps = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    ref = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    out = engine.rollout(actions.to(DEV), s0, P, mode="exact", perms=None if perms is None else perms.to(DEV),
+                         eps=None if eps is None else eps.to(DEV))
+    assert_returns_close(out, ref)
+
+
+@pytest.mark.parametrize("case", SIZES[:7], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_fast_mode_replayed_through_oracle(engine, case):
+    """FAST mode end to end (balanced member schedule + Philox eps drawn in-kernel): export the kernel's own
+    randomness through the ABI, replay it through the oracle's explicit row->member form, compare returns."""
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    seed, sid = 1234, 77
+    nwg, r = engine.fast_geometry(pop, P)
+    out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
+    sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
+    eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
+    rows = torch.arange(pop * P)
+    wg = ((rows // P) // (16 * r)) * P + rows % P
+    members = torch.stack([sched[0 if om.propagation == "fixed_model" else t][wg].long() for t in range(H)])
+    ref = po.rollout(om, actions, s0, P, members=members, eps=eps)
+    assert_returns_close(out, ref)
+    # the schedule is balanced: every member slot gets floor/ceil(nwg / M) workgroups at every step
+    M = len(om.active_members)
+    for t in range(H):
+        counts = torch.bincount(sched[t].long(), minlength=M)
+        assert counts.max() - counts.min() <= 1 and counts.sum() == nwg
+    if om.propagation == "fixed_model":
+        assert (sched == sched[0]).all()  # TS-infinity: one member per particle for the whole horizon
+
+
+def test_known_answer_dummy_model(engine):
+    """tests/core/test_models.py:365-385 on the GPU: returns == H (H+1) / 2 * a, P, H in 1..9."""
+    from test_oracle_golden import dummy_model_as_mlp
+
+    act_dim = 2
+    om = dummy_model_as_mlp(act_dim)
+    engine.set_model(to_spec(om, 1, act_dim))
+    for P in range(1, 10):
+        for H in (1, 2, 5, 9):
+            acts = torch.stack([torch.ones(H, act_dim), 2 * torch.ones(H, act_dim)])
+            expected = H * (H + 1) * acts[..., 0, 0] / 2
+            for mode in ("exact", "fast"):
+                out = engine.rollout(acts.to(DEV), np.zeros(1), P, mode=mode)
+                assert torch.allclose(expected, out.cpu()), (P, H, mode)
+
+
+def test_fast_normals_are_standard_normal(engine):
+    om = po.make_synthetic_model(17, 6, ensemble_size=5, hid=16)
+    engine.set_model(to_spec(om, 17, 6))
+    z = engine.fast_normals(30, 10000, seed=5, stream_id=3).double().flatten().cpu()
+    n = z.numel()
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs((z**4).mean() - 3) < 0.05
+    z2 = engine.fast_normals(30, 10000, seed=5, stream_id=4).double().flatten().cpu()
+    assert abs(torch.corrcoef(torch.stack([z, z2]))[0, 1]) < 5 / np.sqrt(n)  # streams are independent
+    assert torch.equal(engine.fast_normals(3, 50, seed=5, stream_id=3).cpu(), engine.fast_normals(3, 50, seed=5, stream_id=3).cpu())
+
+
+def test_fast_mode_statistics_match_exact_mode(engine):
+    """T5: same action sequences evaluated in FAST mode (Philox, block-balanced TS1) and in EXACT mode (torch
+    perms / eps): per-candidate return means agree within 4 sigma of the seed-to-seed spread."""
+    obs, act, pop, P, H = 17, 6, 64, 20, 10
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=64, seed=2)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(0)
+    actions = (torch.rand(pop, H, act, generator=g) * 2 - 1).to(DEV)
+    s0 = np.zeros(obs, np.float32)
+    n = 24
+    fast = torch.stack([engine.rollout(actions, s0, P, mode="fast", seed=9, stream_id=i) for i in range(n)]).cpu()
+    exact = []
+    for i in range(n):
+        perms = torch.stack([torch.randperm(pop * P, generator=g) for _ in range(H)]).to(DEV)
+        eps = torch.randn(H, pop * P, obs, generator=g).to(DEV)
+        exact.append(engine.rollout(actions, s0, P, mode="exact", perms=perms, eps=eps))
+    exact = torch.stack(exact).cpu()
+    se = torch.sqrt(fast.var(0) / n + exact.var(0) / n)
+    zscore = (fast.mean(0) - exact.mean(0)) / se
+    assert zscore.abs().max() < 4.5, zscore.abs().max()
+    assert abs(zscore.mean()) < 4.5 / np.sqrt(pop)
+    ratio = fast.var(0).mean() / exact.var(0).mean()  # spread of the particle-mean estimator is comparable
+    assert 0.6 < ratio < 1.6, ratio
+
+
+def test_fast_mode_is_deterministic_and_seed_sensitive(engine):
+    om, actions, s0, _, _ = _random_case(17, 6, 50, 10, 8, ensemble_size=5, hid=64)
+    engine.set_model(to_spec(om, 17, 6))
+    a = engine.rollout(actions.to(DEV), s0, 10, mode="fast", seed=1, stream_id=2)
+    b = engine.rollout(actions.to(DEV), s0, 10, mode="fast", seed=1, stream_id=2)
+    c = engine.rollout(actions.to(DEV), s0, 10, mode="fast", seed=1, stream_id=3)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_linearity_in_particles_full_size(engine):
+    """Size-independent property at cfg2 scale: with a deterministic model every particle of a candidate is
+    identical, so returns do not depend on P, and candidates are independent of their batch neighbours."""
+    obs, act, pop, H = 17, 6, 500, 30
+    om = po.make_synthetic_model(obs, act, ensemble_size=1, hid=200, deterministic=True, propagation="expectation")
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(0)
+    actions = (torch.rand(pop, H, act, generator=g) * 2 - 1).to(DEV)
+    s0 = np.zeros(obs, np.float32)
+    r1 = engine.rollout(actions, s0, 1, mode="fast")
+    r20 = engine.rollout(actions, s0, 20, mode="fast")
+    assert torch.allclose(r1, r20, rtol=0, atol=1e-5)
+    sub = engine.rollout(actions[100:137].contiguous(), s0, 20, mode="fast")
+    assert torch.allclose(sub, r20[100:137], rtol=0, atol=1e-5)
+    rex = engine.rollout(actions, s0, 20, mode="exact")
+    assert torch.allclose(rex, r20, rtol=0, atol=1e-5)
+
+
+def test_error_behaviour(engine):
+    import hipets
+
+    om = po.make_synthetic_model(17, 6, ensemble_size=5, hid=16)
+    engine.set_model(to_spec(om, 17, 6))
+    acts = torch.zeros(3, 4, 6, device=DEV)
+    with pytest.raises(hipets.HipetsError, match="multiple of the number of models"):  # gaussian_mlp.py:195-200
+        engine.rollout(acts, np.zeros(17), 4, mode="exact", perms=torch.zeros(4, 12, dtype=torch.int64, device=DEV))
+    with pytest.raises(hipets.HipetsError, match="needs opts.perms"):
+        engine.rollout(acts, np.zeros(17), 5, mode="exact")
+    with pytest.raises(ValueError):
+        engine.rollout(torch.zeros(3, 4, 5, device=DEV), np.zeros(17), 5)
+    with pytest.raises(ValueError):
+        engine.rollout(acts, np.zeros(16), 5)
+    with pytest.raises(ValueError):
+        engine.rollout(acts.cpu(), np.zeros(17), 5)
+
+
+def test_weights_resnapshot_after_training_step(engine):
+    """Engine reads live parameters again after they change (ModelTrainer hook, model_trainer.py:288-296)."""
+    om, actions, s0, perms, eps = _random_case(17, 6, 20, 5, 4, ensemble_size=5, hid=32)
+    engine.set_model(to_spec(om, 17, 6))
+    a = engine.rollout(actions.to(DEV), s0, 5, mode="exact", perms=perms.to(DEV), eps=eps.to(DEV))
+    om.weights[1] = om.weights[1] * 1.5
+    om.elite_models = [0, 2, 3, 4, 1]
+    engine.set_model(to_spec(om, 17, 6))
+    b = engine.rollout(actions.to(DEV), s0, 5, mode="exact", perms=perms.to(DEV), eps=eps.to(DEV))
+    assert not torch.allclose(a, b)
+    assert_returns_close(b, po.rollout(om, actions, s0, 5, perms=perms, eps=eps))

@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: model snapshot validation, config plumbing, sharding maths."""
+import numpy as np
+import pytest
+import torch
+
+import hipets
+from hipets import dist as hdist
+from hipets.model import ModelSpec, UnsupportedModelError
+from hipets.planning import _instantiate, complete_agent_cfg
+
+
+def small_spec(**kw):
+    E, obs, act, hid = 3, 5, 2, 8
+    d = dict(
+        weights=[torch.zeros(E, obs + act, hid), torch.zeros(E, hid, hid), torch.zeros(E, hid, 2 * obs)],
+        biases=[torch.zeros(E, 1, hid), torch.zeros(E, 1, hid), torch.zeros(E, 1, 2 * obs)],
+        obs_dim=obs, act_dim=act, min_logvar=-10 * torch.ones(1, obs), max_logvar=0.5 * torch.ones(1, obs),
+    )
+    d.update(kw)
+    return ModelSpec(**d)
+
+
+def test_spec_derived_fields_and_flops():
+    s = small_spec(elite_models=[0, 2])
+    s.validate()
+    assert (s.in_dim, s.hid, s.out_dim, s.ensemble_size, s.members) == (7, 8, 5, 3, [0, 2])
+    assert s.flops_per_candidate_step() == 2 * (7 * 8 + 8 * 8 + 8 * 10)
+
+
+def test_cfg2_flops_match_survey():
+    """262 800 FLOP per candidate-step for obs 17 / act 6 / hid 200 / 4 hidden layers."""
+    E = 1
+    ws = [torch.zeros(E, 23, 200)] + [torch.zeros(E, 200, 200)] * 3 + [torch.zeros(E, 200, 34)]
+    s = ModelSpec(weights=ws, biases=[torch.zeros(E, 1, w.shape[2]) for w in ws], obs_dim=17, act_dim=6,
+                  min_logvar=torch.zeros(1, 17), max_logvar=torch.zeros(1, 17))
+    assert s.flops_per_candidate_step() == 262800
+
+
+@pytest.mark.parametrize("kw,exc", [
+    (dict(activation="gelu"), UnsupportedModelError),
+    (dict(propagation="nope"), ValueError),
+    (dict(reward="my_reward"), UnsupportedModelError),
+    (dict(reward=None), UnsupportedModelError),
+    (dict(termination="my_term"), UnsupportedModelError),
+    (dict(obs_process="custom"), UnsupportedModelError),
+    (dict(obs_dim=6), UnsupportedModelError),
+])
+def test_unsupported_models_are_rejected_not_approximated(kw, exc):
+    with pytest.raises(exc):
+        small_spec(**kw).validate()
+
+
+class _Lin:
+    def __init__(self, w, b):
+        self.weight, self.bias, self.use_bias = torch.nn.Parameter(w), torch.nn.Parameter(b), True
+
+
+class _FakeMLP:
+    def __init__(self, spec, act):
+        self.hidden_layers = [[_Lin(w, b), act] for w, b in zip(spec.weights[:-1], spec.biases[:-1])]
+        self.mean_and_logvar = _Lin(spec.weights[-1], spec.biases[-1])
+        self.min_logvar, self.max_logvar = spec.min_logvar, spec.max_logvar
+        self.elite_models, self.propagation_method, self.deterministic = None, "random_model", False
+
+    def parameters(self):
+        for layer in self.hidden_layers:
+            yield layer[0].weight
+            yield layer[0].bias
+        yield self.mean_and_logvar.weight
+
+
+def halfcheetah(act, next_obs):
+    return next_obs[:, :1]
+
+
+def no_termination(act, next_obs):
+    return torch.zeros(len(next_obs), 1, dtype=torch.bool)
+
+
+class _Space:
+    def __init__(self, n):
+        self.shape = (n,)
+        self.low, self.high = -np.ones(n), np.ones(n)
+
+
+class _FakeModelEnv:
+    def __init__(self, act_module=torch.nn.SiLU()):
+        s = small_spec()
+
+        class DM:
+            pass
+
+        self.dynamics_model = DM()
+        self.dynamics_model.model = _FakeMLP(s, act_module)
+        self.dynamics_model.input_normalizer = None
+        self.dynamics_model.obs_process_fn = None
+        self.dynamics_model.target_is_delta = True
+        self.dynamics_model.no_delta_list = []
+        self.dynamics_model.learned_rewards = False
+        self.reward_fn, self.termination_fn = halfcheetah, no_termination
+        self.observation_space, self.action_space = _Space(5), _Space(2)
+
+
+def test_spec_from_duck_typed_model_env():
+    me = _FakeModelEnv()
+    spec = hipets.spec_from_model_env(me)
+    assert spec.activation == "silu" and spec.reward == "halfcheetah" and spec.termination == "no_termination"
+    assert spec.obs_dim == 5 and spec.act_dim == 2 and len(spec.weights) == 3
+
+
+def test_spec_rejects_unknown_activation_and_python_reward():
+    with pytest.raises(UnsupportedModelError):
+        hipets.spec_from_model_env(_FakeModelEnv(torch.nn.GELU()))
+    me = _FakeModelEnv()
+    me.reward_fn = lambda a, o: o[:, :1]
+    with pytest.raises(UnsupportedModelError):
+        hipets.spec_from_model_env(me)
+
+
+def test_complete_agent_cfg_fills_placeholders():
+    cfg = dict(_target_="hipets.TrajectoryOptimizerAgent", action_lb="???", action_ub="???", planning_horizon=3)
+    complete_agent_cfg(_FakeModelEnv(), cfg)
+    assert cfg["action_lb"] == [-1.0, -1.0] and cfg["action_ub"] == [1.0, 1.0]
+
+
+def test_instantiate_resolves_target_and_drops_placeholders():
+    obj = _instantiate(dict(_target_="fractions.Fraction", numerator=3, denominator="???"))
+    assert obj == 3
+
+
+def test_shard_bounds_cover_population():
+    for pop, world in [(500, 8), (500, 1), (7, 8), (2000, 4), (1001, 3)]:
+        spans = [hdist.shard_bounds(pop, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == pop
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [b - a for a, b in (hdist.shard_bounds(500, 8, r) for r in range(8))] == [63, 63, 63, 63, 62, 62, 62, 62]

@@ -1,0 +1,199 @@
+"""Pins the oracle against the UNMODIFIED reference (imported from /root/reference through
+oracle/ref_stubs).  Runs only in the build container; skipped wherever the reference is absent
+(e.g. the GPU box), where tests/golden/*.npz take over."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pets_oracle as po
+from oracle.ref_bridge import build_reference_model_env, import_reference, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="reference not mounted")
+
+
+@pytest.fixture(scope="module")
+def mbrl():
+    return import_reference()
+
+
+CASES = [
+    dict(obs=17, act=6, mkw=dict(ensemble_size=5, hid=40, seed=0, no_delta_list=[0, 3]), pop=20, P=5, H=4),
+    dict(obs=4, act=1, mkw=dict(ensemble_size=5, hid=32, seed=1, reward="cartpole", termination="cartpole"), pop=15, P=5, H=10),
+    dict(obs=8, act=2, mkw=dict(ensemble_size=7, hid=16, seed=2, elite=[1, 2, 4, 5, 6], propagation="fixed_model",
+                                termination="walker2d"), pop=10, P=5, H=5),
+    dict(obs=6, act=2, mkw=dict(ensemble_size=3, hid=16, seed=3, propagation="expectation", normalizer="f32",
+                                termination="ant", activation="sigmoid"), pop=6, P=2, H=5),
+    dict(obs=5, act=2, mkw=dict(ensemble_size=2, hid=16, seed=4, termination="inverted_pendulum", reward="inverted_pendulum",
+                                normalizer="none"), pop=8, P=3, H=6),
+    dict(obs=20, act=7, mkw=dict(ensemble_size=2, hid=16, seed=5, reward="pusher", activation="leaky_relu"), pop=4, P=2, H=3),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"obs{c['obs']}_{c['mkw'].get('propagation', 'random_model')}")
+def test_rollout_bitwise_vs_reference(mbrl, case):
+    om = po.make_synthetic_model(case["obs"], case["act"], **case["mkw"])
+    g = torch.Generator().manual_seed(9)
+    actions = torch.rand(case["pop"], case["H"], case["act"], generator=g) * 2 - 1
+    s0 = (np.random.default_rng(3).standard_normal(case["obs"]) * 0.1).astype(np.float32)
+    if om.termination == "walker2d":
+        s0[0] = 1.0
+    if om.termination == "ant":
+        s0[0] = 0.6
+    me, _, _ = build_reference_model_env(om, case["obs"], case["act"], generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(42)
+    ref = me.evaluate_action_sequences(actions, s0, case["P"])
+    torch.manual_seed(42)
+    mine = po.rollout(om, actions, s0, case["P"], global_rng=True, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(ref, mine)
+
+
+def test_member_map_equals_perm(mbrl):
+    """The oracle's explicit row->member map (used to check FAST mode) == the reference's perm form."""
+    om = po.make_synthetic_model(17, 6, ensemble_size=5, hid=24, seed=0)
+    B, H, P = 50, 3, 5
+    g = torch.Generator().manual_seed(0)
+    actions = torch.rand(B // P, H, 6, generator=g)
+    s0 = np.zeros(17, np.float32)
+    perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+    eps = torch.randn(H, B, 17, generator=g)
+    members = torch.empty(H, B, dtype=torch.long)
+    for t in range(H):
+        members[t][perms[t]] = torch.arange(B) // (B // 5)
+    a = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    b = po.rollout(om, actions, s0, P, members=members, eps=eps)
+    assert torch.allclose(a, b, rtol=0, atol=1e-6)
+
+
+def _quadratic(target, nan_at=None):
+    def f(x):
+        v = -((x - target) ** 2).sum(dim=(1, 2)).clone()
+        if nan_at is not None:
+            v[nan_at] = float("nan")
+        return v
+
+    return f
+
+
+@pytest.mark.parametrize("clipped,return_mean", [(False, True), (False, False), (True, True)])
+def test_cem_bitwise_vs_reference(mbrl, clipped, return_mean):
+    H, A, pop = 5, 2, 30
+    lb, ub = [[-1.0, -2.0]] * H, [[1.0, 0.5]] * H
+    obj = _quadratic(torch.linspace(-0.3, 0.3, H * A).view(H, A), nan_at=2)
+    opt = mbrl.planning.CEMOptimizer(3, 0.2, pop, lb, ub, 0.1, "cpu", return_mean_elites=return_mean, clipped_normal=clipped)
+    torch.manual_seed(0)
+    ref = opt.optimize(obj, x0=torch.zeros(H, A))
+    torch.manual_seed(0)
+    mine = po.cem_optimize(obj, torch.zeros(H, A), torch.tensor(lb), torch.tensor(ub), 3, 0.2, pop, 0.1,
+                           return_mean_elites=return_mean, clipped_normal=clipped)
+    assert torch.equal(ref, mine)
+
+
+def test_mppi_bitwise_vs_reference_two_calls(mbrl):
+    """Two consecutive plans: pins the persistent mean and the past_action aliasing quirk (Appendix B4/B6)."""
+    H, A, pop = 6, 2, 40
+    lb, ub = [[-1.0, -1.0]] * H, [[1.0, 1.0]] * H
+    obj = _quadratic(torch.full((H, A), 0.2))
+    opt = mbrl.planning.MPPIOptimizer(3, pop, 0.9, 1.0, 0.9, lb, ub, "cpu")
+    st = po.MPPIState(H, A)
+    torch.manual_seed(1)
+    r1, r2 = opt.optimize(obj), opt.optimize(obj)
+    torch.manual_seed(1)
+    m1 = po.mppi_optimize(obj, st, torch.tensor(lb), torch.tensor(ub), 3, pop, 0.9, 1.0, 0.9)
+    m2 = po.mppi_optimize(obj, st, torch.tensor(lb), torch.tensor(ub), 3, pop, 0.9, 1.0, 0.9)
+    assert torch.equal(r1, m1) and torch.equal(r2, m2)
+
+
+def test_mppi_sigma_is_dead(mbrl):
+    """Appendix B5: sigma does not influence the sampled population."""
+    H, A, pop = 4, 2, 16
+    lb, ub = torch.full((H, A), -1.0), torch.full((H, A), 1.0)
+    obj = _quadratic(torch.zeros(H, A))
+    outs = []
+    for sigma in (0.01, 5.0):
+        torch.manual_seed(3)
+        outs.append(po.mppi_optimize(obj, po.MPPIState(H, A), lb, ub, 2, pop, 0.9, sigma, 0.9))
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_icem_bitwise_vs_reference_two_calls(mbrl):
+    """Two plans: pins coloured noise, population decay, kept-elite shift / append, biased variance."""
+    H, A, pop = 8, 3, 60
+    lb, ub = [[-1.0] * A] * H, [[1.0] * A] * H
+    obj = _quadratic(torch.full((H, A), -0.1), nan_at=1)
+    kw = dict(num_iterations=4, elite_ratio=0.1, population_size=pop, population_decay_factor=1.3,
+              colored_noise_exponent=2.0, keep_elite_frac=0.3, alpha=0.1)
+    opt = mbrl.planning.ICEMOptimizer(lower_bound=lb, upper_bound=ub, device="cpu", return_mean_elites=True,
+                                      population_size_module=5, **kw)
+    st = po.ICEMState()
+    torch.manual_seed(2)
+    r1 = opt.optimize(obj, x0=torch.zeros(H, A))
+    r2 = opt.optimize(obj, x0=r1.clone())
+    torch.manual_seed(2)
+    m1 = po.icem_optimize(obj, st, torch.zeros(H, A), torch.tensor(lb), torch.tensor(ub), return_mean_elites=True,
+                          population_size_module=5, **kw)
+    m2 = po.icem_optimize(obj, st, m1.clone(), torch.tensor(lb), torch.tensor(ub), return_mean_elites=True,
+                          population_size_module=5, **kw)
+    assert torch.equal(r1, m1) and torch.equal(r2, m2)
+
+
+@pytest.mark.parametrize("n", [15, 30, 40])
+def test_powerlaw_noise_bitwise(mbrl, n):
+    import mbrl.util.math as rm
+
+    torch.manual_seed(0)
+    ref = rm.powerlaw_psd_gaussian(2.0, size=(7, 3, n), device="cpu")
+    torch.manual_seed(0)
+    mine = po.powerlaw_psd_gaussian(2.0, size=(7, 3, n))
+    assert torch.equal(ref, mine)
+
+
+def test_truncated_normal_bitwise(mbrl):
+    import mbrl.util.math as rm
+
+    torch.manual_seed(0)
+    ref = rm.truncated_normal_(torch.empty(50, 7))
+    torch.manual_seed(0)
+    mine = po.truncated_normal_(torch.empty(50, 7))
+    assert torch.equal(ref, mine)
+
+
+def test_trajectory_optimizer_shift(mbrl):
+    """trajectory_opt.py:563-568: warm start rolled by replan_freq and refilled with (lb+ub)/2."""
+    import omegaconf
+
+    H, A = 5, 2
+    lbv, ubv = np.array([-1.0, 0.0]), np.array([1.0, 2.0])
+    cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.CEMOptimizer", num_iterations=2, elite_ratio=0.2,
+                                          population_size=20, alpha=0.1, device="cpu", lower_bound="???", upper_bound="???",
+                                          return_mean_elites=True))
+    ref = mbrl.planning.TrajectoryOptimizer(cfg, lbv, ubv, H, replan_freq=2)
+    st = po.TrajectoryOptimizerState(lbv, ubv, H, replan_freq=2)
+    obj = _quadratic(torch.full((H, A), 0.3))
+    torch.manual_seed(0)
+    r = [ref.optimize(obj), ref.optimize(obj)]
+    torch.manual_seed(0)
+    opt = lambda x0: po.cem_optimize(obj, x0, st.lower, st.upper, 2, 0.2, 20, 0.1, return_mean_elites=True)  # noqa: E731
+    m = [st.step(opt), st.step(opt)]
+    assert np.array_equal(r[0], m[0]) and np.array_equal(r[1], m[1])
+    assert torch.equal(ref.previous_solution, st.previous_solution)
+
+
+def test_spec_extraction_from_live_reference_objects(mbrl):
+    """hipets.spec_from_model_env reads the real mbrl objects (seam 3) and reproduces the OracleModel."""
+    import hipets
+
+    om = po.make_synthetic_model(18, 6, ensemble_size=7, hid=16, seed=0, elite=[0, 1, 3, 4, 6], obs_process="halfcheetah",
+                                 no_delta_list=[2], termination="hopper")
+    me, dm, model = build_reference_model_env(om, 18, 6, generator=torch.Generator())
+    spec = hipets.spec_from_model_env(me)
+    assert spec.members == [0, 1, 3, 4, 6] and spec.activation == "silu" and spec.propagation == "random_model"
+    assert spec.obs_process == "halfcheetah" and spec.reward == "halfcheetah" and spec.termination == "hopper"
+    assert spec.no_delta_list == [2] and spec.norm_mean.dtype == torch.float64 and spec.in_dim == 24 and spec.out_dim == 18
+    for a, b in zip(spec.weights, om.weights):
+        assert torch.equal(a, b)
+    v0 = hipets.model_version(me)
+    with torch.no_grad():
+        model.hidden_layers[0][0].weight.add_(1.0)
+    assert hipets.model_version(me) != v0
+    model.set_elite([0, 1, 2, 3, 4])
+    assert hipets.spec_from_model_env(me).members == [0, 1, 2, 3, 4]
