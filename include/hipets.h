@@ -104,6 +104,8 @@ typedef struct {
     float* trace_next_obs;   /* [H,B,obs_dim]                                                     */
     float* trace_rewards;    /* [H,B] reward of the step before termination masking               */
     int32_t rows_per_group;  /* 0 = auto; else force R (row tiles of 16 per workgroup)            */
+    int64_t* phase_cycles;   /* DEVICE [4,16] optional: per-wave, per-phase shader-cycle counters of     */
+                             /*   workgroup 0, accumulated (profiling aid)                */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -121,7 +123,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* desc, void* stre
 int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t horizon,
                    int32_t num_particles, const hipets_rollout_opts* opts, float* returns, void* stream);
 /* geometry the FAST kernel will use for (pop, P): workgroups and rows per group (for member_schedule) */
-int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t rows_per_group,
+int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t rows_per_group,
                          int32_t* n_workgroups, int32_t* row_tiles);
 
 /* FAST-mode randomness, exported so a FAST rollout can be replayed through a reference implementation:

@@ -120,9 +120,9 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
     }
 }
 
-size_t lds_for(const hipets_engine* e, int R) {
+size_t lds_for(const hipets_engine* e, int R, int horizon) {
     const ModelDev& md = e->md;
-    return rollout_smem_bytes(kTile * R, md.ld, md.obs_dim, md.act_dim, md.out_total,
+    return rollout_smem_bytes(kTile * R, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, horizon,
                               md.propagation == HIPETS_PROP_EXPECTATION);
 }
 
@@ -133,13 +133,13 @@ int wave_units(int C, int R) {
     return full * R + (rem * R + kWaves - 1) / kWaves;
 }
 
-int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced) {
+int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon) {
     if (forced > 0) return forced;
     const int C = e->md.hidC;
     int best = 1;
     double best_cost = 1e300;
     for (int R = 1; R <= kMaxR; ++R) {
-        if (lds_for(e, R) > e->lds_max) break;
+        if (lds_for(e, R, horizon) > e->lds_max) break;
         const long long groups = (tiles_total_per_slice + R - 1) / R;
         const long long nwg = groups * slices;
         const long long rounds = (nwg + e->num_cu - 1) / e->num_cu;
@@ -276,7 +276,8 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     int ld = maxK;
     while (ld % 64 != 8) ld += 4;
     md.ld = ld;
-    if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.out_total, md.propagation == HIPETS_PROP_EXPECTATION) > e->lds_max)
+    if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, 64,
+                           md.propagation == HIPETS_PROP_EXPECTATION) > e->lds_max)
         return fail("model too wide for LDS (ld=%d)", md.ld);
 
     if (e->wpack.ensure((size_t)md.wmember * md.M * 4)) return 1;
@@ -329,14 +330,14 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     return 0;
 }
 
-int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t rows_per_group, int32_t* n_workgroups,
-                         int32_t* row_tiles) {
+int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horizon, int32_t rows_per_group,
+                         int32_t* n_workgroups, int32_t* row_tiles) {
     if (!e || !e->has_model) return fail("engine has no model");
     if (pop < 1 || P < 1) return fail("bad pop/P");
     if (rows_per_group < 0 || rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
     const long long tiles = (pop + kTile - 1) / kTile;
-    const int R = choose_R(e, tiles, P, rows_per_group);
-    if (lds_for(e, R) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+    const int R = choose_R(e, tiles, P, rows_per_group, horizon);
+    if (lds_for(e, R, horizon) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
     const long long groups = (tiles + R - 1) / R;
     if (n_workgroups) *n_workgroups = (int)(groups * P);
     if (row_tiles) *row_tiles = R;
@@ -369,6 +370,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     ra.stream_id = o->stream_id;
     ra.trace_next_obs = o->trace_next_obs;
     ra.trace_rewards = o->trace_rewards;
+    ra.phase_cycles = reinterpret_cast<long long*>(o->phase_cycles);
 
     if (o->mode == HIPETS_MODE_EXACT) {
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
@@ -381,8 +383,8 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         }
         const int rpd = (int)(B / domains);
         const long long tiles = (rpd + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, domains, o->rows_per_group);
-        const size_t lds = lds_for(e, R);
+        const int R = choose_R(e, tiles, domains, o->rows_per_group, H);
+        const size_t lds = lds_for(e, R, H);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
         if (e->state.ensure((size_t)B * md.obs_dim * 4) || e->term.ensure((size_t)B)) return 1;
@@ -405,8 +407,8 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         }
     } else if (o->mode == HIPETS_MODE_FAST) {
         const long long tiles = (pop + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, P, o->rows_per_group);
-        const size_t lds = lds_for(e, R);
+        const int R = choose_R(e, tiles, P, o->rows_per_group, H);
+        const size_t lds = lds_for(e, R, H);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
         const int nwg = groups * P;

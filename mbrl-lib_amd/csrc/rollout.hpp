@@ -75,20 +75,55 @@ struct RolloutArgs {
     const int* schedule;   // FAST: [H, nWG] member slot per (step, workgroup)
     float* trace_next_obs;
     float* trace_rewards;
+    long long* phase_cycles;  // optional [4 waves][16 phases] cycle counters of workgroup 0 (profiling aid)
 };
 
-__device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+// D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
+// ("+v"): with the builtin, hipcc's register allocator rotates the accumulators through fresh registers in
+// the unrolled k loop and pays ~45 v_accvgpr_mov/read/write per iteration to undo it at the back edge.
+// Hazards: A/B come from loads (the compiler's s_waitcnt covers asm inputs); back-to-back MFMAs that take
+// the previous D whole as C need no wait states; the first non-MFMA reader of D is fenced by mfma_drain().
+__device__ __forceinline__ void mfma16x16x4(const float a, const float b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// >= 12 wait states between the last 8-pass MFMA and a VALU read of its result (cdna4 ISA, XDL write -> VALU read)
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
+
+// phase profiler: lane 0 of every wave of workgroup 0 accumulates s_memtime deltas per phase into
+// RolloutArgs::phase_cycles[wave][phase] (a profiling aid, off unless the caller passes a buffer)
+struct Prof {
+    long long* slot;  // &phase_cycles[wave * 16]
+    long long t;
+    bool on;
+    __device__ __forceinline__ void mark(int phase) {
+        if (on) {
+            const long long now = clock64();
+            slot[phase] += now - t;
+            t = now;
+        }
+    }
+};
 
 // One wave's share of a layer: CT strided column tiles (c_first + 4*ct) for all R row tiles, plus EX
 // "extra" (column tile, row tile) units taken from the C % 4 leftover column tiles, all accumulated
 // in the same k loop so the MFMA pipe always has >= 2 independent accumulators in flight.
+// The k loop is software pipelined by hand with two register buffers: the B fragments (global, L2
+// resident) and A fragments (LDS) of chunk kk+1 are in flight while the 4*(CT*R+EX) MFMAs of chunk kk
+// issue (one wave per SIMD, so nothing else hides the load latency).
+template <int R, int CT, int EX>
+struct GemmFrags {
+    f32x4 b[CT > 0 ? CT : 1];
+    f32x4 bx[EX > 0 ? EX : 1];
+    f32x4 a[R];
+    f32x4 ax[EX > 0 ? EX : 1];
+};
+
 template <int R, int CT, int EX>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC,
                                           const int c_first, const Extras ex,
-                                          const bool apply_act, const int act, const float slope, const int lane) {
+                                          const bool apply_act, const int act, const float slope, const int lane,
+                                          Prof& prof) {
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
     f32x4 acc[CTn][R];
@@ -100,86 +135,131 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
     for (int e = 0; e < EXn; ++e) accx[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const f32x4* wp[CTn];
-    const f32x4* wx[EXn];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) wp[ct] = reinterpret_cast<const f32x4*>(W) + (size_t)(c_first + 4 * ct) * KC * 64 + lane;
     const int exc[3] = {ex.c0, ex.c1, ex.c2};
     const int exr[3] = {ex.r0, ex.r1, ex.r2};
+    // 32-bit element offsets from W (a member's layer block is < 2^31 floats)
+    int woff[CTn], wxoff[EXn], axoff[EXn];
 #pragma unroll
-    for (int e = 0; e < EX; ++e) wx[e] = reinterpret_cast<const f32x4*>(W) + (size_t)exc[e] * KC * 64 + lane;
+    for (int ct = 0; ct < CT; ++ct) woff[ct] = ((c_first + 4 * ct) * KC * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        wxoff[e] = (exc[e] * KC * 64 + lane) * 4;
+        axoff[e] = exr[e] * 16 * ld;
+    }
     const float* ap = in + (lane & 15) * ld + 4 * (lane >> 4);
+    // biases of this lane's columns: loaded before the k loop so their latency hides behind it
+    float bv[CTn], bvx[EXn];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bv[ct] = bias[(c_first + 4 * ct) * 16 + (lane & 15)];
+#pragma unroll
+    for (int e = 0; e < EX; ++e) bvx[e] = bias[exc[e] * 16 + (lane & 15)];
 
-// (k loop left rolled: the body is already 4*(CT*R+EX) MFMAs)
-    for (int kk = 0; kk < KC; ++kk) {
-        f32x4 b[CTn], bx[EXn], a[R];
+    auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) {
+#if defined(HIPETS_EXP) && (HIPETS_EXP & 1)
+        const int kb = 0;  // experiment: B fragments always from chunk 0 (L1 resident)
+#else
+        const int kb = kk;
+#endif
+#if defined(HIPETS_EXP) && (HIPETS_EXP & 2)
+        const int ka = 0;  // experiment: A fragments always from chunk 0
+#else
+        const int ka = kk;
+#endif
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) b[ct] = wp[ct][(size_t)kk * 64];
+        for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(W + woff[ct] + kb * 256);
 #pragma unroll
-        for (int e = 0; e < EX; ++e) bx[e] = wx[e][(size_t)kk * 64];
+        for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(W + wxoff[e] + kb * 256);
 #pragma unroll
-        for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + kk * 16);
-        f32x4 ax[EXn];
+        for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + ka * 16);
 #pragma unroll
-        for (int e = 0; e < EX; ++e)  // own LDS read (a runtime-indexed register array would go to scratch)
-            ax[e] = *reinterpret_cast<const f32x4*>(ap + exr[e] * 16 * ld + kk * 16);
+        for (int e = 0; e < EX; ++e) f.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + ka * 16);
+    };
+    auto compute = [&](const GemmFrags<R, CT, EX>& f) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[ct][r] = mfma16x16x4(a[r][s], b[ct][s], acc[ct][r]);
+                for (int r = 0; r < R; ++r) mfma16x16x4(f.a[r][s], f.b[ct][s], acc[ct][r]);
 #pragma unroll
-            for (int e = 0; e < EX; ++e) accx[e] = mfma16x16x4(ax[e][s], bx[e][s], accx[e]);
+            for (int e = 0; e < EX; ++e) mfma16x16x4(f.ax[e][s], f.bx[e][s], accx[e]);
         }
-    }
+    };
 
-    // epilogue: D[row = 4*(lane>>4)+i][col = lane&15] -> bias, activation, next layer's A image
-    const int j = lane & 15, g4 = 4 * (lane >> 4);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int col = (c_first + 4 * ct) * 16 + j;
-        const float bv = bias[col];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = acc[ct][r][i] + bv;
-                if (apply_act) v = activate(v, act, slope);
-                out[(r * 16 + g4 + i) * ld + col] = v;
-            }
+    // sched_barrier(0) pins "issue the next chunk's loads, THEN this chunk's MFMAs": without it the machine
+    // scheduler sinks each load group down to its first use and the pipeline degenerates to load->wait->compute.
+    GemmFrags<R, CT, EX> f0, f1;
+    load(f0, 0);
+    const int last = KC - 1;
+    int kk = 0;
+    for (; kk + 1 < KC; kk += 2) {
+        load(f1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(f0, kk + 2 < last ? kk + 2 : last);  // clamped: an even KC reloads the last chunk (unused)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (KC & 1) compute(f0);
+    mfma_drain();
+    __builtin_amdgcn_sched_barrier(0);
+    prof.mark(11);
+
+    // epilogue: D[row = 4*(lane>>4)+i][col = lane&15] -> bias, activation, next layer's A image.
+    // The activation switch is hoisted OUT of the element loops: one compact straight-line body per
+    // activation (a per-element switch made the hot path stream ~12 KB of mostly-skipped code per layer
+    // through the instruction cache: 11k cycles per epilogue instead of ~2k).
+    auto store = [&](auto actfn) {
+        const int j = lane & 15, g4 = 4 * (lane >> 4);
 #pragma unroll
-    for (int e = 0; e < EX; ++e) {
-        const int col = exc[e] * 16 + j;
-        const float bv = bias[col];
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = (c_first + 4 * ct) * 16 + j;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = accx[e][i] + bv;
-            if (apply_act) v = activate(v, act, slope);
-            out[(exr[e] * 16 + g4 + i) * ld + col] = v;
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[(r * 16 + g4 + i) * ld + col] = actfn(acc[ct][r][i] + bv[ct]);
+        }
+#pragma unroll
+        for (int e = 0; e < EX; ++e) {
+            const int col = exc[e] * 16 + j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(exr[e] * 16 + g4 + i) * ld + col] = actfn(accx[e][i] + bvx[e]);
+        }
+    };
+    if (!apply_act) {
+        store([](float x) { return x; });
+    } else {
+        switch (act) {
+            case HIPETS_ACT_SILU: store([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }); break;
+            case HIPETS_ACT_RELU: store([](float x) { return fmaxf(x, 0.0f); }); break;
+            case HIPETS_ACT_LEAKY_RELU: store([slope](float x) { return x > 0.0f ? x : slope * x; }); break;
+            case HIPETS_ACT_TANH: store([](float x) { return tanhf(x); }); break;
+            default: store([](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }); break;
         }
     }
+    prof.mark(13);
 }
 
 template <int R, int CT>
 __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* out, int ld, const float* W,
                                              const float* bias, int KC, int c_first, const Extras ex,
-                                             bool apply_act, int act, float slope, int lane) {
+                                             bool apply_act, int act, float slope, int lane, Prof& prof) {
     switch (nex) {
         case 0:
-            if constexpr (CT > 0) wave_gemm<R, CT, 0>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane);
+            if constexpr (CT > 0) wave_gemm<R, CT, 0>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof);
             break;
-        case 1: wave_gemm<R, CT, 1>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane); break;
-        case 2: wave_gemm<R, CT, 2>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane); break;
-        default: wave_gemm<R, CT, 3>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane); break;
+        case 1: wave_gemm<R, CT, 1>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 2: wave_gemm<R, CT, 2>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
+        default: wave_gemm<R, CT, 3>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
     }
 }
 
 // One linear layer (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS).
 template <int R>
 __device__ __forceinline__ void mlp_layer(const ModelDev& md, const int l, const int member, const float* in,
-                                          float* out, const int wave, const int lane) {
+                                          float* out, const int wave, const int lane, Prof& prof) {
     const LayerMeta lm = md.layers[l];
     const int KC = lm.Kp / kKChunk;
     const int C = lm.Np / kTile;
@@ -196,15 +276,15 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const int l, const
     const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;
     int done = 0;
     while (full - done > 3) {
-        wave_gemm<R, 3, 0>(in, out, md.ld, W, bias, KC, wave + kWaves * done, ex, apply_act, md.activation, md.slope, lane);
+        wave_gemm<R, 3, 0>(in, out, md.ld, W, bias, KC, wave + kWaves * done, ex, apply_act, md.activation, md.slope, lane, prof);
         done += 3;
     }
     const int c_first = wave + kWaves * done;
     switch (full - done) {
-        case 0: wave_gemm_ex<R, 0>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane); break;
-        case 1: wave_gemm_ex<R, 1>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane); break;
-        case 2: wave_gemm_ex<R, 2>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane); break;
-        default: wave_gemm_ex<R, 3>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane); break;
+        case 0: wave_gemm_ex<R, 0>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 1: wave_gemm_ex<R, 1>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 2: wave_gemm_ex<R, 2>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        default: wave_gemm_ex<R, 3>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
     }
 }
 
@@ -298,27 +378,40 @@ __device__ __forceinline__ void rollout_normals4(int rid, int t, int blk, unsign
 struct RolloutSmem {
     float* buf0;
     float* buf1;
-    float* state;   // [ROWS][obs_dim]
-    float* actn;    // [ROWS][act_dim]
-    float* tot;     // [ROWS]
-    float* lrew;    // [ROWS] learned reward of the current step
-    int* term;      // [ROWS]
-    int* rowid;     // [ROWS] global row id (candidate*P + particle) or -1
-    float* expacc;  // [ROWS][out_total] (expectation propagation only)
+    float* state;    // [ROWS][obs_dim]
+    float* actn;     // [2][ROWS][act_dim]  (double buffered: reward(t) reads while input(t+1) is built)
+    float* tot;      // [ROWS]
+    float* lrew;     // [ROWS] learned reward of the current step
+    int* term;       // [ROWS]
+    int* rowid;      // [ROWS] global row id (candidate*P + particle) or -1
+    double* nmean;   // [in_dim] normaliser stats (f64 like the reference)
+    double* nstd;    // [in_dim]
+    float* minlv;    // [out_dim]
+    float* maxlv;    // [out_dim]
+    int* nodelta;    // [obs_dim]
+    int* sched;      // [H] member slot of this workgroup per step (FAST)
+    float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_dim, int act_dim, int out_total,
-                                                     bool expectation) {
+__host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_dim, int act_dim, int in_dim, int out_dim,
+                                                     int out_total, int horizon, bool expectation) {
     size_t n = 0;
     n += 2 * align16((size_t)rows * ld * 4);
     n += align16((size_t)rows * obs_dim * 4);
-    n += align16((size_t)rows * act_dim * 4);
+    n += align16((size_t)2 * rows * act_dim * 4);
     n += 4 * align16((size_t)rows * 4);
+    n += 2 * align16((size_t)in_dim * 8);
+    n += 2 * align16((size_t)out_dim * 4);
+    n += align16((size_t)obs_dim * 4);
+    n += align16((size_t)horizon * 4);
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
+
+// log(1 + e^x) with the hardware exp/log (abs error ~1e-7; F.softplus' threshold-20 branch kept)
+__device__ __forceinline__ float softplus_fast(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
 
 template <int R>
 __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
@@ -330,11 +423,17 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         sm.buf0 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.ld * 4);
         sm.buf1 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.ld * 4);
         sm.state = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.obs_dim * 4);
-        sm.actn = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.act_dim * 4);
+        sm.actn = reinterpret_cast<float*>(p); p += align16((size_t)2 * ROWS * md.act_dim * 4);
         sm.tot = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * 4);
         sm.lrew = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * 4);
         sm.term = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
         sm.rowid = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
+        sm.nmean = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
+        sm.nstd = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
+        sm.minlv = reinterpret_cast<float*>(p); p += align16((size_t)md.out_dim * 4);
+        sm.maxlv = reinterpret_cast<float*>(p); p += align16((size_t)md.out_dim * 4);
+        sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
+        sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
@@ -344,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
     const int wg = blockIdx.x;
 
-    // ---- which rollout rows does this workgroup own -----------------------------------------
+    // ---- which rollout rows does this workgroup own; per-dimension constants into LDS -------------
     int domain = 0;
     if (fast) {
         const int p = wg % ra.P, grp = wg / ra.P;
@@ -352,6 +451,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             const int c = grp * ROWS + s;
             sm.rowid[s] = c < ra.pop ? c * ra.P + p : -1;
         }
+        if (!expectation)
+            for (int t = tid; t < ra.H; t += kThreads) sm.sched[t] = ra.schedule[(size_t)t * gridDim.x + wg];
     } else {
         domain = wg / ra.groups;
         const int j0 = (wg % ra.groups) * ROWS;
@@ -366,6 +467,11 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             sm.rowid[s] = rid;
         }
     }
+    if (md.normalizer != HIPETS_NORM_NONE)
+        for (int i = tid; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = md.norm_std[i]; }
+    if (!md.deterministic)
+        for (int i = tid; i < md.out_dim; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
+    for (int i = tid; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
     __syncthreads();
 
     // ---- initial state ------------------------------------------------------------------------
@@ -383,48 +489,69 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         sm.term[s] = (!fast && rid >= 0) ? (int)ra.term[rid] : 0;
         sm.lrew[s] = 0.f;
     }
-    __syncthreads();
 
     const int nblk = (md.out_dim + 3) / 4;
     const int Kp0 = md.Kp0;
+    Prof prof;
+    prof.on = ra.phase_cycles != nullptr && wg == 0 && lane == 0;
+    prof.slot = ra.phase_cycles + wave * 16;
+    prof.t = prof.on ? clock64() : 0;
+    if (prof.on)  // slot 15: where this wave landed (HW_REG_HW_ID: simd [5:4], cu [11:8])
+        prof.slot[15] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11));
+
+    // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0;
+    // the step's actions (model_env.py:179-182: row r uses candidate r // P) are fetched from HBM here, once,
+    // and kept in actn[t & 1] for the reward function.
+    auto build_input = [&](const int t, const bool fetch_actions) {
+        float* actn_t = sm.actn + (t & 1) * ROWS * md.act_dim;
+        for (int i = tid; i < ROWS * Kp0; i += kThreads) {
+            const int s = i / Kp0, c = i % Kp0;
+            const int rid = sm.rowid[s];
+            float v = 0.f;
+            if (c < md.in_dim && rid >= 0) {
+                if (c < md.obs_in) {
+                    v = processed_obs(sm.state + s * md.obs_dim, c, md.obs_process);
+                } else {
+                    const int a = c - md.obs_in;
+                    if (fetch_actions) {
+                        v = ra.actions[((size_t)(rid / ra.P) * ra.H + t) * md.act_dim + a];
+                        actn_t[s * md.act_dim + a] = v;
+                    } else {
+                        v = actn_t[s * md.act_dim + a];
+                    }
+                }
+                if (md.normalizer == HIPETS_NORM_F64) v = (float)(((double)v - sm.nmean[c]) / sm.nstd[c]);
+                else if (md.normalizer == HIPETS_NORM_F32) v = (v - (float)sm.nmean[c]) / (float)sm.nstd[c];
+            }
+            sm.buf0[s * md.ld + c] = v;
+        }
+    };
+
+    __syncthreads();
+    build_input(ra.t_begin, true);
+    __syncthreads();
+    prof.mark(0);
 
     for (int t = ra.t_begin; t < ra.t_end; ++t) {
-        // ---- actions of this step (model_env.py:179-182: row r uses candidate r // P) ----------
-        for (int i = tid; i < ROWS * md.act_dim; i += kThreads) {
-            const int s = i / md.act_dim, a = i % md.act_dim;
-            const int rid = sm.rowid[s];
-            sm.actn[i] = rid >= 0 ? ra.actions[((size_t)(rid / ra.P) * ra.H + t) * md.act_dim + a] : 0.f;
-        }
-        __syncthreads();
-
         const int n_run = expectation ? md.M : 1;
         float* result = nullptr;
         for (int mi = 0; mi < n_run; ++mi) {
             int member;
             if (expectation) member = mi;
-            else if (fast) member = ra.schedule[(size_t)t * gridDim.x + wg];
+            else if (fast) member = sm.sched[t];
             else member = domain;
-
-            // ---- model input: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116)
-            for (int i = tid; i < ROWS * Kp0; i += kThreads) {
-                const int s = i / Kp0, c = i % Kp0;
-                float v = 0.f;
-                if (c < md.in_dim && sm.rowid[s] >= 0) {
-                    v = c < md.obs_in ? processed_obs(sm.state + s * md.obs_dim, c, md.obs_process)
-                                      : sm.actn[s * md.act_dim + (c - md.obs_in)];
-                    if (md.normalizer == HIPETS_NORM_F64) v = (float)(((double)v - md.norm_mean[c]) / md.norm_std[c]);
-                    else if (md.normalizer == HIPETS_NORM_F32) v = (v - (float)md.norm_mean[c]) / (float)md.norm_std[c];
-                }
-                sm.buf0[s * md.ld + c] = v;
+            if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
+                build_input(t, false);
+                __syncthreads();
             }
-            __syncthreads();
-
             // ---- the MLP: ping-pong through LDS ------------------------------------------------
             float* cur = sm.buf0;
             float* nxt = sm.buf1;
             for (int l = 0; l < md.n_layers; ++l) {
-                mlp_layer<R>(md, l, member, cur, nxt, wave, lane);
+                prof.mark(12);
+                mlp_layer<R>(md, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
+                prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
             result = cur;
@@ -435,8 +562,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                     float v = result[s * md.ld + c];
                     if (!md.deterministic && c >= md.out_dim) {
                         const int d = c - md.out_dim;
-                        v = md.max_lv[d] - softplus_f(md.max_lv[d] - v);
-                        v = md.min_lv[d] + softplus_f(v - md.min_lv[d]);
+                        v = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - v);
+                        v = sm.minlv[d] + softplus_fast(v - sm.minlv[d]);
                     }
                     sm.expacc[i] = mi == 0 ? v : sm.expacc[i] + v;
                 }
@@ -445,19 +572,20 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         }
 
         // ---- sample, delta, next obs (model.py:458-473, one_dim_tr_model.py:280-288) -----------
+        const bool sample = !md.deterministic && (ra.eps != nullptr || ra.use_philox != 0);
         for (int item = tid; item < ROWS * nblk; item += kThreads) {
             const int s = item / nblk, blk = item % nblk;
             const int rid = sm.rowid[s];
             if (rid < 0) continue;
             float nrm[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!md.deterministic) {
+            if (sample) {
                 if (ra.eps) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int d = blk * 4 + q;
                         if (d < md.out_dim) nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
                     }
-                } else if (ra.use_philox) {
+                } else {
                     rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
                 }
             }
@@ -473,15 +601,15 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                     mean = result[s * md.ld + d];
                     if (!md.deterministic) {
                         lv = result[s * md.ld + md.out_dim + d];
-                        lv = md.max_lv[d] - softplus_f(md.max_lv[d] - lv);  // gaussian_mlp.py:152
-                        lv = md.min_lv[d] + softplus_f(lv - md.min_lv[d]);  // :153
+                        lv = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - lv);  // gaussian_mlp.py:152
+                        lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
                     }
                 }
                 float pred = mean;
-                if (!md.deterministic && (ra.eps || ra.use_philox)) pred = mean + sqrtf(expf(lv)) * nrm[q];
+                if (sample) pred = mean + __builtin_sqrtf(__expf(lv)) * nrm[q];  // model.py:471-473
                 if (d < md.obs_dim) {
                     float nobs = pred;
-                    if (md.target_is_delta && !md.no_delta[d]) nobs = pred + sm.state[s * md.obs_dim + d];
+                    if (md.target_is_delta && !sm.nodelta[d]) nobs = pred + sm.state[s * md.obs_dim + d];
                     sm.state[s * md.obs_dim + d] = nobs;
                     if (ra.trace_next_obs) ra.trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
                 } else {
@@ -490,13 +618,15 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             }
         }
         __syncthreads();
+        prof.mark(9);
 
-        // ---- reward, termination, masked accumulation (model_env.py:124-129, :186-188) ---------
+        // ---- reward, termination, masked accumulation (model_env.py:124-129, :186-188) of step t, and, in the
+        // same barrier interval, the model input of step t+1 (both only READ the new state) ------------------
         for (int s = tid; s < ROWS; s += kThreads) {
             const int rid = sm.rowid[s];
             if (rid < 0) continue;
             const float* st = sm.state + s * md.obs_dim;
-            const float* ac = sm.actn + s * md.act_dim;
+            const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
             float r = reward_eval(st, ac, md.obs_dim, md.act_dim, md.reward_fn, sm.lrew[s]);
             const bool done = term_eval(st, md.obs_dim, md.term_fn);
             if (ra.trace_rewards) ra.trace_rewards[(size_t)t * ra.B + rid] = r;
@@ -504,7 +634,9 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             sm.term[s] = sm.term[s] | (done ? 1 : 0);
             sm.tot[s] += r;
         }
+        if (t + 1 < ra.t_end) build_input(t + 1, true);
         __syncthreads();
+        prof.mark(10);
     }
 
     // ---- write back -------------------------------------------------------------------------------

@@ -111,7 +111,8 @@ class Engine:
                 perms: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, seed: int = 0,
                 stream_id: int = 0, member_schedule: Optional[torch.Tensor] = None,
                 trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
-                rows_per_group: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
+                phase_cycles: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -141,7 +142,7 @@ class Engine:
         else:
             o.fast_eps = _ptr(eps)
             if member_schedule is not None:
-                nwg, _ = self.fast_geometry(pop, num_particles, rows_per_group)
+                nwg, _ = self.fast_geometry(pop, num_particles, H, rows_per_group)
                 _check_dev(member_schedule, torch.int32, dev, "member_schedule", (H, nwg))
                 o.member_schedule = _ptr(member_schedule)
         o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
@@ -152,6 +153,9 @@ class Engine:
             _check_dev(trace_rewards, torch.float32, dev, "trace_rewards", (H, B))
             o.trace_rewards = _ptr(trace_rewards)
         o.rows_per_group = int(rows_per_group)
+        if phase_cycles is not None:
+            _check_dev(phase_cycles, torch.int64, dev, "phase_cycles", (4, 16))
+            o.phase_cycles = _ptr(phase_cycles)
         if out is None:
             out = torch.empty(pop, dtype=torch.float32, device=dev)
         else:
@@ -161,9 +165,10 @@ class Engine:
                                                 num_particles, C.byref(o), _ptr(out), _stream(dev)))
         return out
 
-    def fast_geometry(self, pop: int, num_particles: int, rows_per_group: int = 0):
+    def fast_geometry(self, pop: int, num_particles: int, horizon: int, rows_per_group: int = 0):
         nwg, r = C.c_int32(), C.c_int32()
-        _lib.check(self._lib.hipets_fast_geometry(self._h, pop, num_particles, rows_per_group, C.byref(nwg), C.byref(r)))
+        _lib.check(self._lib.hipets_fast_geometry(self._h, pop, num_particles, horizon, rows_per_group, C.byref(nwg),
+                                                  C.byref(r)))
         return nwg.value, r.value
 
     def fast_schedule(self, horizon: int, n_workgroups: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:

@@ -92,7 +92,7 @@ def test_fast_mode_replayed_through_oracle(engine, case):
     om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
     engine.set_model(to_spec(om, obs, act))
     seed, sid = 1234, 77
-    nwg, r = engine.fast_geometry(pop, P)
+    nwg, r = engine.fast_geometry(pop, P, H)
     out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
