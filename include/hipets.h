@@ -104,7 +104,7 @@ typedef struct {
     float* trace_next_obs;   /* [H,B,obs_dim]                                                     */
     float* trace_rewards;    /* [H,B] reward of the step before termination masking               */
     int32_t rows_per_group;  /* 0 = auto; else force R (row tiles of 16 per workgroup)            */
-    int64_t* phase_cycles;   /* DEVICE [4,16] optional: per-wave, per-phase shader-cycle counters of     */
+    int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
                              /*   workgroup 0, accumulated (profiling aid)                */
 } hipets_rollout_opts;
 

@@ -9,8 +9,14 @@ namespace hipets {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kWave = 64;          // CDNA wavefront
-constexpr int kThreads = 256;      // 4 waves per workgroup = one per SIMD
-constexpr int kWaves = kThreads / kWave;
+#ifndef HIPETS_WAVES
+#define HIPETS_WAVES 4
+#endif
+constexpr int kWaves = HIPETS_WAVES;  // waves per workgroup: 4 = one per SIMD (measured best on cfg2: 1.27 ms/rollout);
+                                      // 8 = two per SIMD builds and passes parity but measured 1.31 ms (VALU phases
+                                      // are shared by the SIMD partners and the kernel is capped at 256 VGPRs)
+constexpr int kThreads = kWaves * kWave;
+constexpr int kMaxExtras = 4;         // max leftover (column tile, row tile) units per wave
 constexpr int kTile = 16;          // rows / cols of one v_mfma_f32_16x16x4_f32 tile
 constexpr int kKChunk = 16;        // k extent of one packed B fragment (4 MFMA k-steps of 4)
 
@@ -39,11 +45,11 @@ __device__ __forceinline__ float u01(uint32_t x) {  // (0,1), 24 random bits
 
 // two uniforms -> two standard normals (Box-Muller)
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float r = sqrtf(-2.0f * __logf(u01(a)));
-    float s, c;
-    __sincosf(6.28318530717958647692f * u01(b), &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+    // r = sqrt(-2 ln u1) = sqrt(-2 ln2 * log2 u1); v_sin/v_cos take their argument in revolutions
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u01(a)));
+    const float u = u01(b);
+    n0 = r * __builtin_amdgcn_cosf(u);
+    n1 = r * __builtin_amdgcn_sinf(u);
 }
 
 // 64-bit mix (splitmix64 finaliser) for sort keys of the balanced member schedule

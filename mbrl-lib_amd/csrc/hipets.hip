@@ -128,9 +128,11 @@ size_t lds_for(const hipets_engine* e, int R, int horizon) {
 
 // cost model for the row-tile count R of a workgroup: (sequential workgroup rounds per CU) x (MFMA units
 // the busiest wave issues per hidden layer).  See DESIGN.md "Choosing R".
-int wave_units(int C, int R) {
-    const int full = C / kWaves, rem = C % kWaves;
-    return full * R + (rem * R + kWaves - 1) / kWaves;
+int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (waves w and w + 4 share SIMD w % 4)
+    const int full = C / kWaves, rem = C % kWaves, nu = rem * R;
+    int simd[4] = {0, 0, 0, 0};
+    for (int w = 0; w < kWaves; ++w) simd[w % 4] += full * R + (w < nu ? (nu - w + kWaves - 1) / kWaves : 0);
+    return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
 }
 
 int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon) {
@@ -263,7 +265,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         lms[l].Np = up16(Ns[l]);
         lms[l].woff = woff;
         lms[l].boff = boff;
-        lms[l].pad_ = 0;
+        lms[l].tail_steps = (Ks[l] - (lms[l].Kp - 16) + 3) / 4;
         woff += (long long)lms[l].Kp * lms[l].Np;
         boff += lms[l].Np;
         maxK = std::max(maxK, std::max(lms[l].Kp, lms[l].Np));

@@ -27,12 +27,12 @@ namespace hipets {
 struct LayerMeta {
     int Kp, Np;          // K, N padded to multiples of 16
     int boff;            // float offset of the layer's bias inside a member block
-    int pad_;
+    int tail_steps;      // MFMA k-steps (of 4) of the last chunk that hold real weights: ceil((K - (Kp - 16)) / 4)
     long long woff;      // float offset of the layer's packed weights inside a member block
 };
 
-struct Extras {  // up to 3 leftover (column tile, row tile) units of one wave
-    int c0, c1, c2, r0, r1, r2;
+struct Extras {  // up to kMaxExtras leftover (column tile, row tile) units of one wave
+    int c0, c1, c2, c3, r0, r1, r2, r3;
 };
 
 struct ModelDev {
@@ -75,7 +75,7 @@ struct RolloutArgs {
     const int* schedule;   // FAST: [H, nWG] member slot per (step, workgroup)
     float* trace_next_obs;
     float* trace_rewards;
-    long long* phase_cycles;  // optional [4 waves][16 phases] cycle counters of workgroup 0 (profiling aid)
+    long long* phase_cycles;  // optional [kWaves][16 phases] cycle counters of workgroup 0 (profiling aid)
 };
 
 // D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
@@ -88,6 +88,11 @@ __device__ __forceinline__ void mfma16x16x4(const float a, const float b, f32x4&
 }
 // >= 12 wait states between the last 8-pass MFMA and a VALU read of its result (cdna4 ISA, XDL write -> VALU read)
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
+
+// Column c of an activation row lives at LDS position lds_col(c): inside every 16-wide k chunk the 4x4 block
+// (k-step s, lane group g) is stored transposed, so the lane group g of the A fragment reads its 4 k-steps
+// {16kk + 4s + g : s = 0..3} with ONE ds_read_b128 at [16kk + 4g, +3].
+__device__ __forceinline__ int lds_col(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
 
 // phase profiler: lane 0 of every wave of workgroup 0 accumulates s_memtime deltas per phase into
 // RolloutArgs::phase_cycles[wave][phase] (a profiling aid, off unless the caller passes a buffer)
@@ -104,7 +109,7 @@ struct Prof {
     }
 };
 
-// One wave's share of a layer: CT strided column tiles (c_first + 4*ct) for all R row tiles, plus EX
+// One wave's share of a layer: CT strided column tiles (c_first + kWaves*ct) for all R row tiles, plus EX
 // "extra" (column tile, row tile) units taken from the C % 4 leftover column tiles, all accumulated
 // in the same k loop so the MFMA pipe always has >= 2 independent accumulators in flight.
 // The k loop is software pipelined by hand with two register buffers: the B fragments (global, L2
@@ -121,7 +126,7 @@ struct GemmFrags {
 template <int R, int CT, int EX>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC,
-                                          const int c_first, const Extras ex,
+                                          const int tail_steps, const int c_first, const Extras ex,
                                           const bool apply_act, const int act, const float slope, const int lane,
                                           Prof& prof) {
     constexpr int CTn = CT > 0 ? CT : 1;
@@ -135,12 +140,12 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
     for (int e = 0; e < EXn; ++e) accx[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int exc[3] = {ex.c0, ex.c1, ex.c2};
-    const int exr[3] = {ex.r0, ex.r1, ex.r2};
+    const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
+    const int exr[kMaxExtras] = {ex.r0, ex.r1, ex.r2, ex.r3};
     // 32-bit element offsets from W (a member's layer block is < 2^31 floats)
     int woff[CTn], wxoff[EXn], axoff[EXn];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) woff[ct] = ((c_first + 4 * ct) * KC * 64 + lane) * 4;
+    for (int ct = 0; ct < CT; ++ct) woff[ct] = ((c_first + kWaves * ct) * KC * 64 + lane) * 4;
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
         wxoff[e] = (exc[e] * KC * 64 + lane) * 4;
@@ -150,7 +155,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // biases of this lane's columns: loaded before the k loop so their latency hides behind it
     float bv[CTn], bvx[EXn];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bv[ct] = bias[(c_first + 4 * ct) * 16 + (lane & 15)];
+    for (int ct = 0; ct < CT; ++ct) bv[ct] = bias[(c_first + kWaves * ct) * 16 + (lane & 15)];
 #pragma unroll
     for (int e = 0; e < EX; ++e) bvx[e] = bias[exc[e] * 16 + (lane & 15)];
 
@@ -174,15 +179,53 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
         for (int e = 0; e < EX; ++e) f.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + ka * 16);
     };
-    auto compute = [&](const GemmFrags<R, CT, EX>& f) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+    // Hazards the compiler cannot see inside asm: (1) a VALU write (e.g. a phi copy of an accumulator) must be
+    // >= 2 wait states ahead of the MFMA that reads it -> s_nop 1 opens every k-step; (2) an MFMA that takes the
+    // previous MFMA's D as C back-to-back (issue interval 32 < dependent latency 40 cycles) reads a stale C on
+    // VGPR accumulators -> a wave whose whole share is ONE unit alternates two accumulators (even / odd k-steps).
+    constexpr bool kSplit = (CT * R + EX) == 1;
+    f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto kstep = [&](const GemmFrags<R, CT, EX>& f, const int s) {
+        asm volatile("s_nop 1");
+        if constexpr (kSplit) {
+            f32x4& dst = (s & 1) ? acc_odd : (CT ? acc[0][0] : accx[0]);
+            if constexpr (CT) mfma16x16x4(f.a[0][s], f.b[0][s], dst);
+            else mfma16x16x4(f.ax[0][s], f.bx[0][s], dst);
+        } else {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < R; ++r) mfma16x16x4(f.a[r][s], f.b[ct][s], acc[ct][r]);
 #pragma unroll
             for (int e = 0; e < EX; ++e) mfma16x16x4(f.ax[e][s], f.bx[e][s], accx[e]);
+        }
+    };
+    auto compute = [&](const GemmFrags<R, CT, EX>& f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kstep(f, s);
+    };
+    // The compiler models an asm MFMA as an ordinary instruction whose result is ready immediately, so any VALU
+    // copy of an accumulator it places right behind one (phi copies where control flow merges) would read the
+    // register before the matrix pipe has written it.  drain_all() = wait out the pipe, then re-define every
+    // accumulator through an empty asm so such copies can only be scheduled after the wait.  It ends every
+    // conditional arm below and follows the main loop; the loop body itself is branch-free and in place.
+    auto drain_all = [&]() {
+        mfma_drain();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acc[ct][r]));
+#pragma unroll
+        for (int e = 0; e < EX; ++e) asm volatile("" : "+v"(accx[e]));
+        asm volatile("" : "+v"(acc_odd));
+    };
+    // last chunk: only the k-steps that hold real (non-padding) weights, e.g. 2 of 4 for K = 200
+    auto compute_tail = [&](const GemmFrags<R, CT, EX>& f) {
+        switch (tail_steps) {
+            case 1: kstep(f, 0); drain_all(); break;
+            case 2: kstep(f, 0); kstep(f, 1); drain_all(); break;
+            case 3: kstep(f, 0); kstep(f, 1); kstep(f, 2); drain_all(); break;
+            default: kstep(f, 0); kstep(f, 1); kstep(f, 2); kstep(f, 3); drain_all(); break;
         }
     };
 
@@ -192,17 +235,32 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     load(f0, 0);
     const int last = KC - 1;
     int kk = 0;
-    for (; kk + 1 < KC; kk += 2) {
+    for (; kk + 2 < KC; kk += 2) {  // chunks kk, kk+1 are not the last one
         load(f1, kk + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(f0);
         __builtin_amdgcn_sched_barrier(0);
-        load(f0, kk + 2 < last ? kk + 2 : last);  // clamped: an even KC reloads the last chunk (unused)
+        load(f0, kk + 2);
         __builtin_amdgcn_sched_barrier(0);
         compute(f1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (KC & 1) compute(f0);
+    if (kk > 0) drain_all();
+    if (kk + 1 < KC) {  // two chunks left: kk (full) and kk+1 (tail)
+        load(f1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_tail(f1);
+    } else {  // one chunk left
+        compute_tail(f0);
+    }
+    (void)last;
+    if constexpr (kSplit) {
+        mfma_drain();
+        if constexpr (CT) acc[0][0] += acc_odd;
+        else accx[0] += acc_odd;
+    }
     mfma_drain();
     __builtin_amdgcn_sched_barrier(0);
     prof.mark(11);
@@ -212,10 +270,13 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // activation (a per-element switch made the hot path stream ~12 KB of mostly-skipped code per layer
     // through the instruction cache: 11k cycles per epilogue instead of ~2k).
     auto store = [&](auto actfn) {
-        const int j = lane & 15, g4 = 4 * (lane >> 4);
+        // hidden layers feed the next layer's A fragments -> chunk-transposed column; the output layer is read
+        // back by dimension -> plain column
+        const int j = apply_act ? lds_col(lane & 15) : (lane & 15);
+        const int g4 = 4 * (lane >> 4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int col = (c_first + 4 * ct) * 16 + j;
+            const int col = (c_first + kWaves * ct) * 16 + j;
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -244,15 +305,16 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 
 template <int R, int CT>
 __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* out, int ld, const float* W,
-                                             const float* bias, int KC, int c_first, const Extras ex,
+                                             const float* bias, int KC, int tail_steps, int c_first, const Extras ex,
                                              bool apply_act, int act, float slope, int lane, Prof& prof) {
     switch (nex) {
         case 0:
-            if constexpr (CT > 0) wave_gemm<R, CT, 0>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof);
+            if constexpr (CT > 0) wave_gemm<R, CT, 0>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
             break;
-        case 1: wave_gemm<R, CT, 1>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
-        case 2: wave_gemm<R, CT, 2>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
-        default: wave_gemm<R, CT, 3>(in, out, ld, W, bias, KC, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 1: wave_gemm<R, CT, 1>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 2: wave_gemm<R, CT, 2>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 3: wave_gemm<R, CT, 3>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        default: wave_gemm<R, CT, 4>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
     }
 }
 
@@ -273,18 +335,25 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const int l, const
     ex.c0 = kWaves * full + wave / R;              ex.r0 = wave % R;
     ex.c1 = kWaves * full + (wave + kWaves) / R;     ex.r1 = (wave + kWaves) % R;
     ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; ex.r2 = (wave + 2 * kWaves) % R;
-    const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;
+    ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
+    const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;  // <= kMaxExtras since rem < kWaves, R <= 4
+    // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
+    // fragment registers must fit the 256 VGPRs two waves per SIMD leave each wave)
+    constexpr int kMaxCT = kWaves >= 8 ? 2 : 3;
     int done = 0;
-    while (full - done > 3) {
-        wave_gemm<R, 3, 0>(in, out, md.ld, W, bias, KC, wave + kWaves * done, ex, apply_act, md.activation, md.slope, lane, prof);
-        done += 3;
+    while (full - done > kMaxCT) {
+        wave_gemm<R, kMaxCT, 0>(in, out, md.ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, md.activation, md.slope, lane, prof);
+        done += kMaxCT;
     }
     const int c_first = wave + kWaves * done;
     switch (full - done) {
-        case 0: wave_gemm_ex<R, 0>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
-        case 1: wave_gemm_ex<R, 1>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
-        case 2: wave_gemm_ex<R, 2>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
-        default: wave_gemm_ex<R, 3>(nex, in, out, md.ld, W, bias, KC, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 0: wave_gemm_ex<R, 0>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 1: wave_gemm_ex<R, 1>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 2: wave_gemm_ex<R, 2>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        default:
+            if constexpr (kMaxCT >= 3)
+                wave_gemm_ex<R, 3>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof);
+            break;
     }
 }
 
@@ -499,36 +568,77 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     if (prof.on)  // slot 15: where this wave landed (HW_REG_HW_ID: simd [5:4], cu [11:8])
         prof.slot[15] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11));
 
-    // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0;
-    // the step's actions (model_env.py:179-182: row r uses candidate r // P) are fetched from HBM here, once,
-    // and kept in actn[t & 1] for the reward function.
-    auto build_input = [&](const int t, const bool fetch_actions) {
-        float* actn_t = sm.actn + (t & 1) * ROWS * md.act_dim;
-        for (int i = tid; i < ROWS * Kp0; i += kThreads) {
-            const int s = i / Kp0, c = i % Kp0;
+    // the step's actions (model_env.py:179-182: row r uses candidate r // P) come from HBM.  Each thread owns up to
+    // kPrefetch (row, action-dim) elements; their addresses are fixed for the whole horizon up to the t * A term, and
+    // the loads for step t+1 are issued at the top of step t's sampling phase so their latency hides behind it.
+    constexpr int kPrefetch = 4;
+    const int n_act = ROWS * md.act_dim;
+    long long act_base[kPrefetch];  // element offset of (candidate, t = 0, a); -1 = nothing to fetch
+#pragma unroll
+    for (int q = 0; q < kPrefetch; ++q) {
+        const int i = tid + q * kThreads;
+        act_base[q] = -1;
+        if (i < n_act) {
+            const int s = i / md.act_dim, a = i % md.act_dim;
             const int rid = sm.rowid[s];
-            float v = 0.f;
-            if (c < md.in_dim && rid >= 0) {
-                if (c < md.obs_in) {
-                    v = processed_obs(sm.state + s * md.obs_dim, c, md.obs_process);
-                } else {
-                    const int a = c - md.obs_in;
-                    if (fetch_actions) {
-                        v = ra.actions[((size_t)(rid / ra.P) * ra.H + t) * md.act_dim + a];
-                        actn_t[s * md.act_dim + a] = v;
-                    } else {
-                        v = actn_t[s * md.act_dim + a];
-                    }
+            if (rid >= 0) act_base[q] = (long long)(rid / ra.P) * ra.H * md.act_dim + a;
+        }
+    }
+    auto fetch_actions_rest = [&](const int t) {  // elements beyond kPrefetch per thread (very wide action spaces)
+        float* actn_t = sm.actn + (t & 1) * n_act;
+        for (int i = tid + kPrefetch * kThreads; i < n_act; i += kThreads) {
+            const int s = i / md.act_dim, a = i % md.act_dim;
+            const int rid = sm.rowid[s];
+            actn_t[i] = rid >= 0 ? ra.actions[((size_t)(rid / ra.P) * ra.H + t) * md.act_dim + a] : 0.f;
+        }
+    };
+    auto fetch_actions_issue = [&](const int t, float (&av)[kPrefetch]) {
+#pragma unroll
+        for (int q = 0; q < kPrefetch; ++q) av[q] = act_base[q] >= 0 ? ra.actions[act_base[q] + (long long)t * md.act_dim] : 0.f;
+    };
+    auto fetch_actions_commit = [&](const int t, const float (&av)[kPrefetch]) {
+        float* actn_t = sm.actn + (t & 1) * n_act;
+#pragma unroll
+        for (int q = 0; q < kPrefetch; ++q) {
+            const int i = tid + q * kThreads;
+            if (i < n_act) actn_t[i] = av[q];
+        }
+        fetch_actions_rest(t);
+    };
+
+    // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0.
+    // One item = (row, 4 consecutive columns): four independent LDS-read -> f64 normalise -> LDS-write chains.
+    const int kq = Kp0 >> 2;  // column quads per row (Kp0 is a multiple of 16)
+    auto build_input = [&](const int t) {
+        const float* actn_t = sm.actn + (t & 1) * n_act;
+        for (int i = tid; i < ROWS * kq; i += kThreads) {
+            const int s = i / kq, cq = i % kq;
+            const bool valid = sm.rowid[s] >= 0;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * cq + q;
+                v[q] = 0.f;
+                if (c < md.in_dim && valid) {
+                    v[q] = c < md.obs_in ? processed_obs(sm.state + s * md.obs_dim, c, md.obs_process)
+                                         : actn_t[s * md.act_dim + (c - md.obs_in)];
+                    if (md.normalizer == HIPETS_NORM_F64) v[q] = (float)(((double)v[q] - sm.nmean[c]) / sm.nstd[c]);
+                    else if (md.normalizer == HIPETS_NORM_F32) v[q] = (v[q] - (float)sm.nmean[c]) / (float)sm.nstd[c];
                 }
-                if (md.normalizer == HIPETS_NORM_F64) v = (float)(((double)v - sm.nmean[c]) / sm.nstd[c]);
-                else if (md.normalizer == HIPETS_NORM_F32) v = (v - (float)sm.nmean[c]) / (float)sm.nstd[c];
             }
-            sm.buf0[s * md.ld + c] = v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sm.buf0[s * md.ld + lds_col(4 * cq + q)] = v[q];
         }
     };
 
     __syncthreads();
-    build_input(ra.t_begin, true);
+    {
+        float av[kPrefetch];
+        fetch_actions_issue(ra.t_begin, av);
+        fetch_actions_commit(ra.t_begin, av);
+    }
+    __syncthreads();
+    build_input(ra.t_begin);
     __syncthreads();
     prof.mark(0);
 
@@ -541,7 +651,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             else if (fast) member = sm.sched[t];
             else member = domain;
             if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
-                build_input(t, false);
+                build_input(t);
                 __syncthreads();
             }
             // ---- the MLP: ping-pong through LDS ------------------------------------------------
@@ -573,6 +683,9 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
 
         // ---- sample, delta, next obs (model.py:458-473, one_dim_tr_model.py:280-288) -----------
         const bool sample = !md.deterministic && (ra.eps != nullptr || ra.use_philox != 0);
+        const bool more = t + 1 < ra.t_end;
+        float av[kPrefetch];
+        if (more) fetch_actions_issue(t + 1, av);  // HBM latency hides behind this phase
         for (int item = tid; item < ROWS * nblk; item += kThreads) {
             const int s = item / nblk, blk = item % nblk;
             const int rid = sm.rowid[s];
@@ -589,10 +702,12 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                     rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
                 }
             }
+            // straight-line over the 4 dims of the block (indices clamped, stores predicated) so the four
+            // dependent chains (LDS read -> 2 softplus -> exp -> sqrt -> fma) interleave
+            float pred[4], prev[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int d = blk * 4 + q;
-                if (d >= md.out_dim) break;
+                const int d = min(blk * 4 + q, md.out_dim - 1);
                 float mean, lv = 0.f;
                 if (expectation) {
                     mean = sm.expacc[s * md.out_total + d] / (float)md.M;
@@ -605,18 +720,23 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                         lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
                     }
                 }
-                float pred = mean;
-                if (sample) pred = mean + __builtin_sqrtf(__expf(lv)) * nrm[q];  // model.py:471-473
+                pred[q] = sample ? mean + __builtin_sqrtf(__expf(lv)) * nrm[q] : mean;  // model.py:471-473
+                const int do_ = min(d, md.obs_dim - 1);
+                prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = blk * 4 + q;
                 if (d < md.obs_dim) {
-                    float nobs = pred;
-                    if (md.target_is_delta && !sm.nodelta[d]) nobs = pred + sm.state[s * md.obs_dim + d];
+                    const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
                     sm.state[s * md.obs_dim + d] = nobs;
                     if (ra.trace_next_obs) ra.trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
-                } else {
-                    sm.lrew[s] = pred;  // learned reward = last output (one_dim_tr_model.py:287)
+                } else if (d < md.out_dim) {
+                    sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
                 }
             }
         }
+        if (more) fetch_actions_commit(t + 1, av);
         __syncthreads();
         prof.mark(9);
 
@@ -634,7 +754,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             sm.term[s] = sm.term[s] | (done ? 1 : 0);
             sm.tot[s] += r;
         }
-        if (t + 1 < ra.t_end) build_input(t + 1, true);
+        if (more) build_input(t + 1);
         __syncthreads();
         prof.mark(10);
     }
@@ -711,7 +831,8 @@ __global__ void export_normals_kernel(float* out, int H, int B, int out_dim, uns
 }
 
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
-//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*(lane>>4) + s][16*c + (lane&15)]   (0 outside K x N)
+//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + (lane&15)]   (0 outside K x N)
+// so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
 __global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
                                     int Np, long long member_stride, long long layer_off) {
     const long long per_member = (long long)Kp * Np;
@@ -724,7 +845,7 @@ __global__ void pack_weights_kernel(float* dst, const float* src, const int* mem
     const int KC = Kp / 16;
     const int kk = (int)(r % KC);
     const int c = (int)(r / KC);
-    const int k = 16 * kk + 4 * (lane >> 4) + s;
+    const int k = 16 * kk + 4 * s + (lane >> 4);  // MFMA k-step s of a chunk covers k = 16 kk + 4 s + {0,1,2,3}
     const int n = 16 * c + (lane & 15);
     float v = 0.f;
     if (k < K && n < N) v = src[((size_t)members[m] * K + k) * N + n];

@@ -154,7 +154,7 @@ class Engine:
             o.trace_rewards = _ptr(trace_rewards)
         o.rows_per_group = int(rows_per_group)
         if phase_cycles is not None:
-            _check_dev(phase_cycles, torch.int64, dev, "phase_cycles", (4, 16))
+            _check_dev(phase_cycles, torch.int64, dev, "phase_cycles", (8, 16))
             o.phase_cycles = _ptr(phase_cycles)
         if out is None:
             out = torch.empty(pop, dtype=torch.float32, device=dev)
