@@ -162,6 +162,32 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
                      float* mu, float* dispersion, float* best_value, float* best_solution, int32_t* elite_idx,
                      void* stream);
 
+/* population[elite_idx] -> dst (the persistent ICEMOptimizer.elite, trajectory_opt.py:476): rows of src
+ * [n_src, D] selected by index DEVICE int32 [rows].                                                          */
+int hipets_gather_rows(hipets_engine* e, int32_t rows, int32_t dim, const float* src, const int32_t* index, float* dst,
+                       void* stream);
+
+/* ---- MPPIOptimizer pieces (mbrl/planning/trajectory_opt.py:238-311) -------------------------------------- */
+/* noise + beta-smoothing recurrence + clipping (:262-295).  mean DEVICE [H,A] (already shifted, :257-258),
+ * past_action DEVICE [A], z DEVICE [pop,H,A] optional injected truncated normals, population DEVICE out.     */
+int hipets_mppi_sample(hipets_engine* e, int32_t pop, int32_t horizon, int32_t act_dim, double beta, const float* mean,
+                       const float* past_action, const float* lower, const float* upper, const float* z, uint64_t seed,
+                       uint64_t stream_id, float* population, void* stream);
+/* NaN -> -1e-10, exp(gamma (v - max v)) weights, weighted mean (:296-309).  values DEVICE [pop] in place.     */
+int hipets_mppi_update(hipets_engine* e, int32_t pop, int32_t horizon, int32_t act_dim, double gamma, float* values,
+                       const float* population, float* mean, void* stream);
+
+/* ---- ICEMOptimizer pieces (mbrl/planning/trajectory_opt.py:391-487, mbrl/util/math.py:318-396) ------------ */
+/* coloured-noise population (:433-441): n rows of population DEVICE [>= n, H, A].  normals DEVICE
+ * [2, n, A, H/2+1] optional injected unit normals (real, imaginary parts of the spectrum).                   */
+int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t horizon, int32_t act_dim, double exponent, const float* mu,
+                       const float* var, const float* lower, const float* upper, const float* normals, uint64_t seed,
+                       uint64_t stream_id, float* population, void* stream);
+/* kept elites shifted one step with a fresh tail action (:450-462).  kept DEVICE [keep,H,A]; end_noise DEVICE
+ * [keep, A] optional injected N(0,1); out DEVICE [keep,H,A].                                                   */
+int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t horizon, int32_t act_dim, const float* kept, const float* mu,
+                      const float* var, const float* end_noise, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+
 /* Whole CEMOptimizer.optimize with the engine's rollout as objective, no host round trip
  * (replaces trajectory_opt.py:142-188 + the closure at :743-748).  x0/lower/upper DEVICE [H,A];
  * out DEVICE [H,A] = mu if return_mean_elites else best.  FAST mode rollouts. `scratch` may be

@@ -11,6 +11,7 @@
 
 #include "../../include/hipets.h"
 #include "cem.hpp"
+#include "optim.hpp"
 #include "rollout.hpp"
 
 using namespace hipets;
@@ -489,6 +490,69 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
     while (n2 < c.pop) n2 <<= 1;
     hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, elite_idx);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_gather_rows(hipets_engine* e, int32_t rows, int32_t dim, const float* src, const int32_t* index, float* dst,
+                       void* stream) {
+    if (!e || !src || !index || !dst || rows < 1 || dim < 1) return fail("bad argument");
+    HCHECK(hipSetDevice(e->device));
+    const long long n = (long long)rows * dim;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
+                       dim, src, index, dst);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_mppi_sample(hipets_engine* e, int32_t pop, int32_t H, int32_t A, double beta, const float* mean, const float* past_action,
+                       const float* lower, const float* upper, const float* z, uint64_t seed, uint64_t stream_id,
+                       float* population, void* stream) {
+    if (!e || !mean || !past_action || !lower || !upper || !population) return fail("null argument");
+    if (pop < 1 || H < 1 || A < 1) return fail("bad pop/horizon/act_dim");
+    HCHECK(hipSetDevice(e->device));
+    const int n = pop * A;
+    hipLaunchKernelGGL(mppi_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pop, H, A,
+                       (float)beta, mean, past_action, lower, upper, z, (unsigned long long)seed, (unsigned long long)stream_id,
+                       population);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_mppi_update(hipets_engine* e, int32_t pop, int32_t H, int32_t A, double gamma, float* values, const float* population,
+                       float* mean, void* stream) {
+    if (!e || !values || !population || !mean) return fail("null argument");
+    if (pop < 1 || pop > 12000 || H < 1 || A < 1) return fail("population_size %d outside [1, 12000]", pop);
+    HCHECK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(mppi_update_kernel, dim3(1), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4,
+                       reinterpret_cast<hipStream_t>(stream), pop, H * A, (float)gamma, values, population, mean);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t H, int32_t A, double exponent, const float* mu, const float* var,
+                       const float* lower, const float* upper, const float* normals, uint64_t seed, uint64_t stream_id,
+                       float* population, void* stream) {
+    if (!e || !mu || !var || !lower || !upper || !population) return fail("null argument");
+    if (n < 1 || A < 1) return fail("bad n/act_dim");
+    if (H < 2 || H > kMaxHorizon) return fail("iCEM horizon %d outside [2, %d]", H, kMaxHorizon);
+    HCHECK(hipSetDevice(e->device));
+    const int total = n * A;
+    hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), n, H, A,
+                       (float)exponent, mu, var, lower, upper, normals, (unsigned long long)seed, (unsigned long long)stream_id,
+                       population);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t H, int32_t A, const float* kept, const float* mu, const float* var,
+                      const float* end_noise, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!e || !kept || !mu || !var || !out) return fail("null argument");
+    if (keep < 1 || H < 1 || A < 1) return fail("bad keep/horizon/act_dim");
+    HCHECK(hipSetDevice(e->device));
+    const int n = keep * H * A;
+    hipLaunchKernelGGL(icem_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keep, H, A, kept,
+                       mu, var, end_noise, (unsigned long long)seed, (unsigned long long)stream_id, out);
     HCHECK(hipGetLastError());
     return 0;
 }

@@ -11,6 +11,8 @@ from .planning import (  # noqa: F401
     Agent,
     CEMOptimizer,
     HipTrajectoryEvalFn,
+    ICEMOptimizer,
+    MPPIOptimizer,
     Optimizer,
     TrajectoryOptimizer,
     TrajectoryOptimizerAgent,

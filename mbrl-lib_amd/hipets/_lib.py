@@ -69,6 +69,11 @@ SYMBOLS = {
     "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hipets_gather_rows": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "hipets_mppi_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_mppi_update": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
+    "hipets_icem_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_icem_shift": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_plan_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
     "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),

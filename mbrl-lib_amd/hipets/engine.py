@@ -225,6 +225,68 @@ class Engine:
             _lib.check(self._lib.hipets_cem_refit(self._h, C.byref(p), _ptr(values), _ptr(population), _ptr(mu), _ptr(dispersion),
                                                   _ptr(best_value), _ptr(best_solution), _ptr(elite_idx), _stream(dev)))
 
+    def gather_rows(self, src: torch.Tensor, index: torch.Tensor, out: torch.Tensor):
+        dev = self.device
+        rows, dim = int(index.numel()), int(out.numel() // max(1, index.numel()))
+        _check_dev(src, torch.float32, dev, "src")
+        _check_dev(index, torch.int32, dev, "index")
+        _check_dev(out, torch.float32, dev, "out", numel=rows * dim)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_gather_rows(self._h, rows, dim, _ptr(src), _ptr(index), _ptr(out), _stream(dev)))
+        return out
+
+    def mppi_sample(self, pop, H, A, beta, mean, past_action, lower, upper, population, z=None, seed=0, stream_id=0):
+        dev = self.device
+        for n_, t in (("mean", mean), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, numel=H * A)
+        _check_dev(past_action, torch.float32, dev, "past_action", numel=A)
+        _check_dev(population, torch.float32, dev, "population", numel=pop * H * A)
+        if z is not None:
+            _check_dev(z, torch.float32, dev, "z", numel=pop * H * A)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_mppi_sample(self._h, pop, H, A, float(beta), _ptr(mean), _ptr(past_action), _ptr(lower),
+                                                    _ptr(upper), _ptr(z), int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1),
+                                                    _ptr(population), _stream(dev)))
+        return population
+
+    def mppi_update(self, pop, H, A, gamma, values, population, mean):
+        dev = self.device
+        _check_dev(values, torch.float32, dev, "values", (pop,))
+        _check_dev(population, torch.float32, dev, "population", numel=pop * H * A)
+        _check_dev(mean, torch.float32, dev, "mean", numel=H * A)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_mppi_update(self._h, pop, H, A, float(gamma), _ptr(values), _ptr(population), _ptr(mean),
+                                                    _stream(dev)))
+        return mean
+
+    def icem_sample(self, n, H, A, exponent, mu, var, lower, upper, population, normals=None, seed=0, stream_id=0):
+        dev = self.device
+        for n_, t in (("mu", mu), ("var", var), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, numel=H * A)
+        _check_dev(population, torch.float32, dev, "population")
+        if population.numel() < n * H * A:
+            raise ValueError("population buffer too small")
+        if normals is not None:
+            _check_dev(normals, torch.float32, dev, "normals", (2, n, A, H // 2 + 1))
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_icem_sample(self._h, n, H, A, float(exponent), _ptr(mu), _ptr(var), _ptr(lower), _ptr(upper),
+                                                    _ptr(normals), int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1),
+                                                    _ptr(population), _stream(dev)))
+        return population
+
+    def icem_shift(self, keep, H, A, kept, mu, var, out, end_noise=None, seed=0, stream_id=0):
+        dev = self.device
+        _check_dev(kept, torch.float32, dev, "kept", numel=keep * H * A)
+        _check_dev(out, torch.float32, dev, "out", numel=keep * H * A)
+        for n_, t in (("mu", mu), ("var", var)):
+            _check_dev(t, torch.float32, dev, n_, numel=H * A)
+        if end_noise is not None:
+            _check_dev(end_noise, torch.float32, dev, "end_noise", numel=keep * A)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_icem_shift(self._h, keep, H, A, _ptr(kept), _ptr(mu), _ptr(var), _ptr(end_noise),
+                                                   int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
     def plan_cem(self, p: CemParams, x0, lower, upper, s0: np.ndarray, num_particles: int, seed: int = 0,
                  plan_id: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.spec is None:

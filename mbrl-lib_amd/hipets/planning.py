@@ -247,6 +247,156 @@ class CEMOptimizer(Optimizer):
         return mu if self.return_mean_elites else best_solution
 
 
+class MPPIOptimizer(Optimizer):
+    """Model Predictive Path Integral optimizer (trajectory_opt.py:191-311) with device-side sampling, smoothing
+    recurrence and importance-weighted update.  Reproduces the reference's behaviour including its quirks
+    (SURVEY.md Appendix B4-B6): ``self.mean`` persists across calls and is NOT cleared by ``agent.reset()``;
+    ``past_action`` aliases the already-shifted ``mean[0]``; ``sigma`` never reaches the population."""
+
+    def __init__(self, num_iterations: int, population_size: int, gamma: float, sigma: float, beta: float,
+                 lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]], device: torch.device,
+                 seed: Optional[int] = None):
+        super().__init__()
+        self.planning_horizon = len(lower_bound)
+        self.population_size = population_size
+        self.action_dimension = len(lower_bound[0])
+        self.engine = get_engine(device)
+        self.device = self.engine.device
+        self.mean = torch.zeros((self.planning_horizon, self.action_dimension), device=self.device, dtype=torch.float32)
+        self.lower_bound = torch.tensor(lower_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.upper_bound = torch.tensor(upper_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.var = sigma**2 * torch.ones_like(self.lower_bound)  # kept for API parity; dead in the reference too
+        self.beta = beta
+        self.gamma = gamma
+        self.refinements = num_iterations
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.calls = 0
+
+    def optimize(self, obj_fun: Callable[[torch.Tensor], torch.Tensor], x0: Optional[torch.Tensor] = None,
+                 callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
+        H, A, pop = self.planning_horizon, self.action_dimension, self.population_size
+        self.calls += 1
+        shifted = self.mean.clone()
+        shifted[:-1] = self.mean[1:]  # :258
+        self.mean = shifted.contiguous()
+        past_action = self.mean[0].clone()  # :257 (a view of the shifted tensor; constant across refinements)
+        population = torch.empty((pop, H, A), device=self.device, dtype=torch.float32)
+        noise = kwargs.get("noise")
+        for k in range(self.refinements):
+            z = None if noise is None else noise[k].to(self.device, torch.float32).contiguous()
+            self.engine.mppi_sample(pop, H, A, self.beta, self.mean, past_action, self.lower_bound, self.upper_bound, population,
+                                    z=z, seed=self.seed, stream_id=self.calls * self.refinements + k)
+            values = obj_fun(population)
+            if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
+                values = values.to(device=self.device, dtype=torch.float32).contiguous()
+            if callback is not None:  # the reference calls back after the NaN filter here (:297-300)
+                values[values.isnan()] = -1e-10
+                callback(population, values, k)
+            new_mean = torch.empty_like(self.mean)
+            self.engine.mppi_update(pop, H, A, self.gamma, values, population, new_mean)
+            self.mean = new_mean
+        return self.mean.clone()
+
+
+class ICEMOptimizer(Optimizer):
+    """Improved CEM (trajectory_opt.py:314-487): decaying population, coloured-noise sampling (device-side inverse
+    real DFT), kept / shifted elites, biased variance refit.  ``self.elite`` persists across calls (Appendix B6)."""
+
+    def __init__(self, num_iterations: int, elite_ratio: float, population_size: int, population_decay_factor: float,
+                 colored_noise_exponent: float, lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]],
+                 keep_elite_frac: float, alpha: float, device: torch.device, return_mean_elites: bool = False,
+                 population_size_module: Optional[int] = None, seed: Optional[int] = None):
+        super().__init__()
+        self.num_iterations = num_iterations
+        self.elite_ratio = elite_ratio
+        self.population_size = population_size
+        self.population_decay_factor = population_decay_factor
+        self.elite_num = np.ceil(self.population_size * self.elite_ratio).astype(np.int32)
+        self.colored_noise_exponent = colored_noise_exponent
+        self.engine = get_engine(device)
+        self.device = self.engine.device
+        self.lower_bound = torch.tensor(lower_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.upper_bound = torch.tensor(upper_bound, device=self.device, dtype=torch.float32).contiguous()
+        self.initial_var = ((self.upper_bound - self.lower_bound) ** 2) / 16
+        self.keep_elite_frac = keep_elite_frac
+        self.keep_elite_size = np.ceil(keep_elite_frac * self.elite_num).astype(np.int32)
+        self.elite = None
+        self.alpha = alpha
+        self.return_mean_elites = return_mean_elites
+        self.population_size_module = population_size_module
+        if self.population_size_module:
+            self.keep_elite_size = self._round_up_to_module(self.keep_elite_size, self.population_size_module)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.calls = 0
+
+    @staticmethod
+    def _round_up_to_module(value: int, module: int) -> int:  # :385-389
+        if value % module == 0:
+            return value
+        return value + (module - value % module)
+
+    def _iteration_size(self, i: int) -> int:  # :419-431
+        n = np.ceil(np.max((self.population_size * self.population_decay_factor**-i, 2 * self.elite_num))).astype(np.int32)
+        if self.population_size_module:
+            n = self._round_up_to_module(n, self.population_size_module)
+        return int(n)
+
+    def optimize(self, obj_fun: Callable[[torch.Tensor], torch.Tensor], x0: Optional[torch.Tensor] = None,
+                 callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
+        eng = self.engine
+        x0 = x0.to(device=self.device, dtype=torch.float32).contiguous()
+        H, A = x0.shape
+        K, keep = int(self.elite_num), int(self.keep_elite_size)
+        self.calls += 1
+        mu = x0.clone()
+        var = self.initial_var.clone().contiguous()
+        best_solution = torch.zeros_like(mu)
+        best_value = torch.full((1,), -float("inf"), device=self.device, dtype=torch.float32)
+        elite_idx = torch.empty(K, dtype=torch.int32, device=self.device)
+        inject = kwargs.get("inject")
+        for i in range(self.num_iterations):
+            n = self._iteration_size(i)
+            inj = inject[i] if inject is not None else {}
+            sid = (self.calls * self.num_iterations + i) * 4
+            extra = 0
+            if self.elite is not None:
+                extra = 1 if (i == self.num_iterations - 1 and i != 0) else keep
+            population = torch.empty((n + extra, H, A), device=self.device, dtype=torch.float32)
+            normals = inj.get("normals")
+            if normals is not None:
+                normals = normals.to(self.device, torch.float32).contiguous()
+            eng.icem_sample(n, H, A, self.colored_noise_exponent, mu, var, self.lower_bound, self.upper_bound, population,
+                            normals=normals, seed=self.seed, stream_id=sid)
+            if self.elite is not None:
+                if "keep_perm" in inj:
+                    perm = inj["keep_perm"].to(self.device)
+                else:  # torch.randperm(elite_num)[:keep] (:446-448): index plumbing, stays a torch op
+                    perm = torch.randperm(K, device=self.device)
+                kept = torch.index_select(self.elite, dim=0, index=perm[:keep]).contiguous()
+                if i == 0:  # :450-462
+                    en = inj.get("end_noise")
+                    if en is not None:
+                        en = en.to(self.device, torch.float32).contiguous()
+                    eng.icem_shift(kept.shape[0], H, A, kept, mu, var, population[n:], end_noise=en, seed=self.seed,
+                                   stream_id=sid + 1)
+                elif i == self.num_iterations - 1:  # :463-464
+                    population[n:] = mu.unsqueeze(0)
+                else:  # :465-466
+                    population[n:] = kept
+            values = obj_fun(population)
+            if callback is not None:
+                callback(population, values, i)
+            if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
+                values = values.to(device=self.device, dtype=torch.float32).contiguous()
+            p = Engine.cem_params(population.shape[0], H, A, self.num_iterations, K, self.alpha, self.return_mean_elites,
+                                  clipped_normal=False, unbiased_var=False)  # biased variance (:479)
+            eng.cem_refit(p, values, population, mu, var, best_value, best_solution, elite_idx)
+            new_elite = torch.empty((K, H, A), device=self.device, dtype=torch.float32)
+            eng.gather_rows(population, elite_idx, new_elite)  # self.elite = population[elite_idx] (:476)
+            self.elite = new_elite
+        return mu if self.return_mean_elites else best_solution
+
+
 # ---------------------------------------------------------------------------------------------
 # TrajectoryOptimizer / Agent
 # ---------------------------------------------------------------------------------------------
@@ -254,6 +404,10 @@ _TARGET_ALIASES = {
     # stock targets are redirected to the fused implementations when an agent of this module builds them
     "mbrl.planning.CEMOptimizer": "hipets.planning.CEMOptimizer",
     "mbrl.planning.trajectory_opt.CEMOptimizer": "hipets.planning.CEMOptimizer",
+    "mbrl.planning.ICEMOptimizer": "hipets.planning.ICEMOptimizer",
+    "mbrl.planning.trajectory_opt.ICEMOptimizer": "hipets.planning.ICEMOptimizer",
+    "mbrl.planning.MPPIOptimizer": "hipets.planning.MPPIOptimizer",
+    "mbrl.planning.trajectory_opt.MPPIOptimizer": "hipets.planning.MPPIOptimizer",
 }
 
 

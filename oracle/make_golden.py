@@ -140,6 +140,86 @@ def gen_cem(name, clipped, return_mean, pop=40, H=6, A=3, iters=4, ratio=0.15, a
     print(f"cem_{name}: oracle==reference bitwise; result[0]={ref[0].tolist()}")
 
 
+def _save_npz(name, meta, arrays):
+    import json
+
+    d = {"x_" + k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    d["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez(os.path.join(OUT, name), **d)
+
+
+def _quad(target, nan_at=None):
+    def f(x):
+        v = -((x - target) ** 2).sum(dim=(1, 2)).clone()
+        if nan_at is not None:
+            v[nan_at] = float("nan")
+        return v
+
+    return f
+
+
+def gen_mppi(pop=48, H=7, A=3, iters=3, gamma=0.9, sigma=1.0, beta=0.9, calls=2):
+    """Two consecutive MPPIOptimizer.optimize calls of the reference (persistent mean, Appendix B4-B6)."""
+    mbrl = import_reference()
+    lb, ub = [[-1.0, -0.5, -2.0][:A]] * H, [[1.0, 1.5, 0.5][:A]] * H
+    target = torch.linspace(-0.3, 0.4, H * A).view(H, A)
+    obj = _quad(target, nan_at=5)
+    opt = mbrl.planning.MPPIOptimizer(iters, pop, gamma, sigma, beta, lb, ub, "cpu")
+    torch.manual_seed(21)
+    refs = [opt.optimize(obj) for _ in range(calls)]
+    torch.manual_seed(21)
+    st = po.MPPIState(H, A)
+    arrays = dict(lower=torch.tensor(lb), upper=torch.tensor(ub), target=target)
+    for c in range(calls):
+        rec = []
+        mine = po.mppi_optimize(obj, st, torch.tensor(lb), torch.tensor(ub), iters, pop, gamma, sigma, beta, record=rec)
+        assert torch.equal(mine, refs[c]), "oracle MPPI != reference"
+        arrays[f"noise{c}"] = torch.stack([r["noise"] for r in rec])
+        arrays[f"populations{c}"] = torch.stack([r["population"] for r in rec])
+        arrays[f"means{c}"] = torch.stack([r["mean"] for r in rec])
+        arrays[f"result{c}"] = refs[c]
+    _save_npz("mppi_two_calls.npz", dict(kind="mppi", pop=pop, H=H, A=A, iters=iters, gamma=gamma, sigma=sigma, beta=beta,
+                                         calls=calls, nan_index=5), arrays)
+    print(f"mppi_two_calls: oracle==reference bitwise; result[0]={refs[-1][0].tolist()}")
+
+
+def gen_icem(pop=60, H=8, A=3, iters=4, ratio=0.1, decay=1.3, exponent=2.0, keep=0.3, alpha=0.1, module=5, calls=2):
+    """Two consecutive ICEMOptimizer.optimize calls of the reference (persistent elite set, kept / shifted elites)."""
+    mbrl = import_reference()
+    lb, ub = [[-1.0] * A] * H, [[1.0, 1.5, 0.5][:A]] * H
+    target = torch.full((H, A), -0.1)
+    obj = _quad(target, nan_at=1)
+    kw = dict(num_iterations=iters, elite_ratio=ratio, population_size=pop, population_decay_factor=decay,
+              colored_noise_exponent=exponent, keep_elite_frac=keep, alpha=alpha)
+    opt = mbrl.planning.ICEMOptimizer(lower_bound=lb, upper_bound=ub, device="cpu", return_mean_elites=True,
+                                      population_size_module=module, **kw)
+    torch.manual_seed(31)
+    x0s, refs = [torch.zeros(H, A)], []
+    for c in range(calls):
+        refs.append(opt.optimize(obj, x0=x0s[-1]))
+        x0s.append(refs[-1].clone())
+    torch.manual_seed(31)
+    st = po.ICEMState()
+    arrays = dict(lower=torch.tensor(lb), upper=torch.tensor(ub), target=target)
+    sizes = []
+    for c in range(calls):
+        rec = []
+        mine = po.icem_optimize(obj, st, x0s[c], torch.tensor(lb), torch.tensor(ub), return_mean_elites=True,
+                                population_size_module=module, record=rec, **kw)
+        assert torch.equal(mine, refs[c]), "oracle iCEM != reference"
+        arrays[f"x0_{c}"] = x0s[c]
+        arrays[f"result{c}"] = refs[c]
+        for i, r in enumerate(rec):
+            for k in ("normals", "noise", "population", "mu", "var", "keep_perm", "end_noise", "elite_idx"):
+                if k in r:
+                    arrays[f"{k}_{c}_{i}"] = r[k]
+        sizes.append([int(r["population"].shape[0]) for r in rec])
+    _save_npz("icem_two_calls.npz", dict(kind="icem", pop=pop, H=H, A=A, iters=iters, elite_ratio=ratio, decay=decay,
+                                         exponent=exponent, keep_frac=keep, alpha=alpha, module=module, calls=calls,
+                                         nan_index=1, evaluated_sizes=sizes), arrays)
+    print(f"icem_two_calls: oracle==reference bitwise; evaluated population sizes {sizes}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -148,6 +228,8 @@ def main():
     gen_cem("truncated_mean", clipped=False, return_mean=True)
     gen_cem("truncated_best", clipped=False, return_mean=False)
     gen_cem("clipped_mean", clipped=True, return_mean=True)
+    gen_mppi()
+    gen_icem()
 
 
 if __name__ == "__main__":

@@ -376,7 +376,7 @@ def rfftfreq(n: int) -> torch.Tensor:  # util/math.py:306-310 (torch >= 1.8 bran
 
 
 def powerlaw_psd_gaussian(exponent: float, size: Sequence[int], fmin: float = 0,
-                          normals: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+                          normals: Optional[Sequence[torch.Tensor]] = None, record_normals: Optional[list] = None) -> torch.Tensor:
     """util/math.py:318-396: coloured noise with PSD ~ 1/f^exponent along the last axis, unit
     variance.  ``normals`` optionally injects (sr, si) of shape size[:-1]+[len(f)]."""
     size = list(size)
@@ -395,12 +395,14 @@ def powerlaw_psd_gaussian(exponent: float, size: Sequence[int], fmin: float = 0,
     dims_to_add = len(size) - 1
     s_scale = s_scale[(None,) * dims_to_add + (Ellipsis,)]
     if normals is None:
-        m = torch.distributions.Normal(loc=0.0, scale=s_scale.flatten())
-        sr = m.sample(tuple(size[:-1]))
-        si = m.sample(tuple(size[:-1]))
-    else:
-        sr = normals[0] * s_scale
-        si = normals[1] * s_scale
+        # torch.distributions.Normal(0, scale).sample(shape) == N(0,1).mul_(scale).add_(0) on CPU (same RNG stream):
+        # drawn here as explicit unit normals so they can be recorded and injected into the device kernel
+        shape = tuple(size[:-1]) + (len(f),)
+        normals = (torch.empty(shape).normal_(0.0, 1.0), torch.empty(shape).normal_(0.0, 1.0))
+    if record_normals is not None:
+        record_normals.append((normals[0].clone(), normals[1].clone()))
+    sr = normals[0] * s_scale + 0.0
+    si = normals[1] * s_scale + 0.0
     if not (samples % 2):
         si[..., -1] = 0
     si[..., 0] = 0
@@ -515,7 +517,7 @@ def mppi_optimize(
         weighted = population * weights
         state.mean = torch.sum(weighted, dim=0) / norm  # :309
         if record is not None:
-            record.append(dict(population=population.clone(), values=values.clone(), mean=state.mean.clone()))
+            record.append(dict(noise=z.clone(), population=population.clone(), values=values.clone(), mean=state.mean.clone()))
     return state.mean.clone()
 
 
@@ -565,22 +567,28 @@ def icem_optimize(
     for i in range(num_iterations):
         n = sizes[i]
         inj = inject[i] if inject is not None else {}
+        rec_i = {}
         if "noise" in inj:
             cn = inj["noise"]
         else:
-            cn = powerlaw_psd_gaussian(colored_noise_exponent, size=(n, A, H)).transpose(1, 2)  # :433-437
+            rn = []
+            cn = powerlaw_psd_gaussian(colored_noise_exponent, size=(n, A, H), normals=inj.get("normals"),
+                                       record_normals=rn).transpose(1, 2)  # :433-437
+            rec_i["normals"] = torch.stack(rn[0])  # [2, n, A, H/2+1] unit normals
+        rec_i["noise"] = cn.clone()
         population = torch.minimum(cn * torch.sqrt(var) + mu, upper)  # :438-440
         population = torch.maximum(population, lower)  # :441
         if state.elite is not None:
             kp = inj["keep_perm"] if "keep_perm" in inj else torch.randperm(K)
+            rec_i["keep_perm"] = kp.clone()
             kept = torch.index_select(state.elite, dim=0, index=kp[:keep])  # :443-449
             if i == 0:  # :450-462
                 m_ = mu[-1, :].repeat(kept.shape[0], 1)
                 s_ = torch.sqrt(var[-1, :]).repeat(kept.shape[0], 1)
-                if "end_noise" in inj:
-                    end_action = (m_ + s_ * inj["end_noise"]).unsqueeze(1)
-                else:
-                    end_action = torch.normal(m_, s_).unsqueeze(1)
+                # torch.normal(mean_tensor, std_tensor) == N(0,1) * std + mean on CPU (same RNG stream)
+                en = inj["end_noise"] if "end_noise" in inj else torch.empty_like(m_).normal_(0.0, 1.0)
+                rec_i["end_noise"] = en.clone()
+                end_action = (en * s_ + m_).unsqueeze(1)
                 shifted = torch.cat((kept[:, 1:, :], end_action), dim=1)
                 population = torch.cat((population, shifted), dim=0)
             elif i == num_iterations - 1:  # :463-464
@@ -599,8 +607,9 @@ def icem_optimize(
             best_val = best_values[0]
             best = population[elite_idx[0]].clone()
         if record is not None:
-            record.append(dict(population=population.clone(), values=values.clone(),
-                               elite_idx=elite_idx.clone(), mu=mu.clone(), var=var.clone()))
+            rec_i.update(population=population.clone(), values=values.clone(), elite_idx=elite_idx.clone(), mu=mu.clone(),
+                         var=var.clone())
+            record.append(rec_i)
     return mu if return_mean_elites else best
 
 

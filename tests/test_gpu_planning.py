@@ -226,3 +226,109 @@ def test_create_agent_for_model_env_and_resnapshot(engine):
         me.dynamics_model.model.mean_and_logvar.weight.add_(0.1)
     agent.act(np.zeros(5, np.float32))
     assert fn._version != v0
+
+
+def _load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return meta, {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x_")}
+
+
+def _quad_dev(target, nan_at):
+    t = target.to(DEV)
+
+    def f(x):
+        v = -((x - t) ** 2).sum(dim=(1, 2)).clone()
+        v[nan_at] = float("nan")
+        return v
+
+    return f
+
+
+def test_mppi_optimizer_matches_reference_two_calls():
+    """hipets.MPPIOptimizer against the reference's golden run: same injected truncated normals, two consecutive
+    plans (pins the persistent mean, the shifted past_action alias and the dead sigma, Appendix B4-B6)."""
+    meta, a = _load_npz("mppi_two_calls.npz")
+    obj = _quad_dev(a["target"], meta["nan_index"])
+    seen = []
+    opt = hipets.MPPIOptimizer(meta["iters"], meta["pop"], meta["gamma"], meta["sigma"], meta["beta"], a["lower"].tolist(),
+                               a["upper"].tolist(), DEV)
+    for c in range(meta["calls"]):
+        out = opt.optimize(obj, noise=list(a[f"noise{c}"]),
+                           callback=lambda p_, v, k, c=c: seen.append((c, k, p_.detach().cpu().clone(), v.detach().cpu().clone())))
+        assert torch.allclose(out.cpu(), a[f"result{c}"], rtol=0, atol=1e-5)
+    for c, k, pop_, v in seen:
+        assert torch.allclose(pop_, a[f"populations{c}"][k], rtol=0, atol=1e-5)
+        assert v[meta["nan_index"]].item() == pytest.approx(-1e-10)
+    other = hipets.MPPIOptimizer(meta["iters"], meta["pop"], meta["gamma"], 5.0, meta["beta"], a["lower"].tolist(),
+                                 a["upper"].tolist(), DEV)  # Appendix B5: sigma is dead
+    assert torch.allclose(other.optimize(obj, noise=list(a["noise0"])).cpu(), a["result0"], rtol=0, atol=1e-5)
+
+
+def test_icem_kernels_and_optimizer_match_reference_two_calls(engine):
+    """Coloured-noise kernel (device inverse real DFT) from the recorded unit normals, then the whole
+    hipets.ICEMOptimizer with the reference's recorded draws injected: population sizes, kept / shifted elites,
+    appended mean, biased variance, persistent elite set across two plans."""
+    meta, a = _load_npz("icem_two_calls.npz")
+    H, A = meta["H"], meta["A"]
+    lower, upper = a["lower"].to(DEV), a["upper"].to(DEV)
+    # kernel level: iteration 0 of call 0 has no appended rows
+    n0 = a["normals_0_0"].shape[1]
+    pop0 = torch.empty(n0, H, A, device=DEV)
+    var0 = (((a["upper"] - a["lower"]) ** 2) / 16).to(DEV)
+    engine.icem_sample(n0, H, A, meta["exponent"], a["x0_0"].to(DEV), var0, lower, upper, pop0, normals=a["normals_0_0"].to(DEV))
+    assert torch.allclose(pop0.cpu(), a["population_0_0"], rtol=0, atol=2e-5)
+    # law of the Philox-driven coloured noise == law of the reference's sampler (oracle, torch RNG): pooled variance
+    # (1 from the sigma normalisation of util/math.py:361-363 plus the un-normalised DC term) and lag-1 correlation
+    big = torch.empty(8000, 30, 6, device=DEV)
+    one = torch.ones(30, 6, device=DEV)
+    engine.icem_sample(8000, 30, 6, 2.0, 0 * one, one, -1e3 * one, 1e3 * one, big, seed=3, stream_id=9)
+    torch.manual_seed(0)
+    ref = po.powerlaw_psd_gaussian(2.0, size=(8000, 6, 30)).transpose(1, 2).double()
+    bigd = big.double().cpu()
+    assert abs(bigd.var().item() - ref.var().item()) < 0.05 and abs(bigd.mean().item()) < 0.03
+    lag = lambda x: (x[:, 1:] * x[:, :-1]).mean().item()  # noqa: E731
+    assert abs(lag(bigd) - lag(ref)) < 0.05 and lag(bigd) > 0.5  # beta = 2: strongly correlated in time
+    # optimizer level
+    obj = _quad_dev(a["target"], meta["nan_index"])
+    opt = hipets.ICEMOptimizer(meta["iters"], meta["elite_ratio"], meta["pop"], meta["decay"], meta["exponent"], a["lower"].tolist(),
+                               a["upper"].tolist(), meta["keep_frac"], meta["alpha"], DEV, return_mean_elites=True,
+                               population_size_module=meta["module"])
+    for c in range(meta["calls"]):
+        inject, sizes = [], []
+        for i in range(meta["iters"]):
+            d = {"normals": a[f"normals_{c}_{i}"]}
+            for k in ("keep_perm", "end_noise"):
+                if f"{k}_{c}_{i}" in a:
+                    d[k] = a[f"{k}_{c}_{i}"]
+            inject.append(d)
+        pops = []
+        out = opt.optimize(obj, x0=a[f"x0_{c}"], inject=inject, callback=lambda p_, v, i: pops.append(p_.detach().cpu().clone()))
+        assert [int(p_.shape[0]) for p_ in pops] == meta["evaluated_sizes"][c]
+        for i, p_ in enumerate(pops):
+            assert torch.allclose(p_, a[f"population_{c}_{i}"], rtol=0, atol=5e-5), (c, i)
+        assert torch.allclose(out.cpu(), a[f"result{c}"], rtol=0, atol=1e-4)
+    assert tuple(opt.elite.shape) == (int(opt.elite_num), H, A)
+
+
+def test_icem_and_mppi_with_engine_objective(engine):
+    """iCEM (cfg4-like: 7 members / 5 elites, Appendix B7) and MPPI driving the fused rollout objective."""
+    from hipets.planning import _BoundObjective
+
+    obs, act, H, P = 17, 6, 10, 20
+    om = po.make_synthetic_model(obs, act, ensemble_size=7, hid=64, seed=5, elite=[0, 1, 2, 3, 4])
+    om.max_logvar = torch.full_like(om.max_logvar, -8.0)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=3)
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    s0 = np.zeros(obs, np.float32)
+    icem = hipets.ICEMOptimizer(4, 0.1, 200, 1.3, 2.0, lb, ub, 0.3, 0.1, DEV, return_mean_elites=True, population_size_module=7, seed=1)
+    mppi = hipets.MPPIOptimizer(4, 210, 0.9, 1.0, 0.9, lb, ub, DEV, seed=1)
+    plans = [icem.optimize(_BoundObjective(fn, s0), x0=torch.zeros(H, act)), mppi.optimize(_BoundObjective(fn, s0))]
+    plans.append(icem.optimize(_BoundObjective(fn, s0), x0=plans[0]))  # second plan uses the kept elites
+    g = torch.Generator().manual_seed(0)
+    cands = torch.cat([torch.stack([p_.cpu() for p_ in plans]), torch.rand(7, H, act, generator=g) * 2 - 1])
+    B = 10 * 50
+    perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+    eps = torch.randn(H, B, obs, generator=g)
+    r = po.rollout(om, cands, s0, 50, perms=perms, eps=eps)
+    assert (r[:3] > r[3:].max() + 0.5).all(), r

@@ -136,3 +136,56 @@ def test_icem_sizes_match_survey():
 
 def test_elite_count_ceil():
     assert po.elite_count(500, 0.1) == 50 and po.elite_count(400, 0.16) == 64  # Appendix B9
+
+
+def _load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return meta, {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x_")}
+
+
+def _quad(target, nan_at):
+    def f(x):
+        v = -((x - target) ** 2).sum(dim=(1, 2)).clone()
+        v[nan_at] = float("nan")
+        return v
+
+    return f
+
+
+def test_mppi_matches_reference_golden():
+    meta, a = _load_npz("mppi_two_calls.npz")
+    st = po.MPPIState(meta["H"], meta["A"])
+    obj = _quad(a["target"], meta["nan_index"])
+    for c in range(meta["calls"]):
+        out = po.mppi_optimize(obj, st, a["lower"], a["upper"], meta["iters"], meta["pop"], meta["gamma"], meta["sigma"],
+                               meta["beta"], noise=list(a[f"noise{c}"]))
+        assert torch.equal(out, a[f"result{c}"])
+
+
+def test_icem_matches_reference_golden():
+    meta, a = _load_npz("icem_two_calls.npz")
+    st = po.ICEMState()
+    obj = _quad(a["target"], meta["nan_index"])
+    for c in range(meta["calls"]):
+        inject = []
+        for i in range(meta["iters"]):
+            d = {"noise": a[f"noise_{c}_{i}"]}
+            for k in ("keep_perm", "end_noise"):
+                if f"{k}_{c}_{i}" in a:
+                    d[k] = a[f"{k}_{c}_{i}"]
+            inject.append(d)
+        rec = []
+        out = po.icem_optimize(obj, st, a[f"x0_{c}"], a["lower"], a["upper"], meta["iters"], meta["elite_ratio"], meta["pop"],
+                               meta["decay"], meta["exponent"], meta["keep_frac"], meta["alpha"], return_mean_elites=True,
+                               population_size_module=meta["module"], inject=inject, record=rec)
+        assert torch.equal(out, a[f"result{c}"])
+        assert [int(r["population"].shape[0]) for r in rec] == meta["evaluated_sizes"][c]
+
+
+def test_colored_noise_from_injected_normals_matches_recorded_noise():
+    """The unit normals recorded next to the reference's coloured noise reproduce it (what the device kernel gets)."""
+    meta, a = _load_npz("icem_two_calls.npz")
+    n = a["normals_0_0"]
+    cn = po.powerlaw_psd_gaussian(meta["exponent"], size=(n.shape[1], meta["A"], meta["H"]), normals=(n[0], n[1])).transpose(1, 2)
+    assert torch.equal(cn, a["noise_0_0"])
