@@ -415,6 +415,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
         const int nwg = groups * P;
+        if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d); shard the population", nwg);
         ra.groups = groups;
         ra.eps = o->fast_eps;
         ra.use_philox = o->fast_eps ? 0 : 1;
@@ -423,7 +424,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
                 ra.schedule = o->member_schedule;
             } else {
                 if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
-                hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), 0, st, e->schedule.as<int>(), nwg, md.M,
+                hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
                                    md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)o->seed,
                                    (unsigned long long)o->stream_id);
                 HCHECK(hipGetLastError());
@@ -446,7 +447,7 @@ int hipets_fast_schedule(hipets_engine* e, int32_t H, int32_t nwg, uint64_t seed
     if (!e || !e->has_model) return fail("engine has no model");
     if (!schedule || H < 1 || nwg < 1) return fail("bad argument");
     HCHECK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
+    hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
                        e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)seed,
                        (unsigned long long)stream_id);
     HCHECK(hipGetLastError());

@@ -799,14 +799,17 @@ __global__ void particle_mean_kernel(const float* totals, float* returns, int po
 // for all steps (TS-infinity).  One block per step.
 __global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, unsigned long long seed,
                                        unsigned long long stream_id) {
+    extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
     const int t = blockIdx.x;
     const unsigned long long tk = fixed ? 0xFFFFFFFFull : (unsigned long long)t;
     const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
+    for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
+    __syncthreads();
     for (int me = threadIdx.x; me < nwg; me += blockDim.x) {
-        const unsigned long long kme = mix64(base + (unsigned long long)me);
+        const unsigned long long kme = keys[me];
         int rank = 0;
         for (int i = 0; i < nwg; ++i) {
-            const unsigned long long ki = mix64(base + (unsigned long long)i);
+            const unsigned long long ki = keys[i];
             rank += (ki < kme) || (ki == kme && i < me);
         }
         sched[(size_t)t * nwg + me] = (int)(((long long)rank * M) / nwg);
