@@ -293,12 +293,12 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         const long long n = (long long)lms[l].Kp * lms[l].Np * md.M;
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e->wpack.as<float>(),
                            reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp,
-                           lms[l].Np, md.wmember, lms[l].woff);
+                           lms[l].Np, md.wmember, lms[l].woff, l < d->n_layers - 1 ? 1 : 0);
         HCHECK(hipGetLastError());
         const int nb = md.M * lms[l].Np;
         hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
                            reinterpret_cast<const float*>(d->biases[l]), e->members.as<int>(), md.M, Ns[l], lms[l].Np, md.bmember,
-                           lms[l].boff);
+                           lms[l].boff, l < d->n_layers - 1 ? 1 : 0);
         HCHECK(hipGetLastError());
     }
     if (d->normalizer != HIPETS_NORM_NONE) {

@@ -153,11 +153,11 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     }
     const float* ap = in + (lane & 15) * ld + 4 * (lane >> 4);
     // biases of this lane's columns: loaded before the k loop so their latency hides behind it
-    float bv[CTn], bvx[EXn];
+    f32x4 bv[CTn], bvx[EXn];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bv[ct] = bias[(c_first + kWaves * ct) * 16 + (lane & 15)];
+    for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + (c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
 #pragma unroll
-    for (int e = 0; e < EX; ++e) bvx[e] = bias[exc[e] * 16 + (lane & 15)];
+    for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
 
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) {
 #if defined(HIPETS_EXP) && (HIPETS_EXP & 1)
@@ -189,15 +189,15 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         asm volatile("s_nop 1");
         if constexpr (kSplit) {
             f32x4& dst = (s & 1) ? acc_odd : (CT ? acc[0][0] : accx[0]);
-            if constexpr (CT) mfma16x16x4(f.a[0][s], f.b[0][s], dst);
-            else mfma16x16x4(f.ax[0][s], f.bx[0][s], dst);
+            if constexpr (CT) mfma16x16x4(f.b[0][s], f.a[0][s], dst);
+            else mfma16x16x4(f.bx[0][s], f.ax[0][s], dst);
         } else {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int r = 0; r < R; ++r) mfma16x16x4(f.a[r][s], f.b[ct][s], acc[ct][r]);
+                for (int r = 0; r < R; ++r) mfma16x16x4(f.b[ct][s], f.a[r][s], acc[ct][r]);
 #pragma unroll
-            for (int e = 0; e < EX; ++e) mfma16x16x4(f.ax[e][s], f.bx[e][s], accx[e]);
+            for (int e = 0; e < EX; ++e) mfma16x16x4(f.bx[e][s], f.ax[e][s], accx[e]);
         }
     };
     auto compute = [&](const GemmFrags<R, CT, EX>& f) {
@@ -269,24 +269,29 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // The activation switch is hoisted OUT of the element loops: one compact straight-line body per
     // activation (a per-element switch made the hot path stream ~12 KB of mostly-skipped code per layer
     // through the instruction cache: 11k cycles per epilogue instead of ~2k).
+    // The product is formed transposed (weights are the MFMA A operand, activations the B operand), so a lane's
+    // accumulator holds 4 CONSECUTIVE LDS columns (16c + 4g .. +3; the weight / bias packing pre-permutes the real
+    // columns so that this holds in the chunk-transposed layout too) of batch row 16r + (lane & 15): one
+    // ds_write_b128 per accumulator instead of four ds_write_b32.
     auto store = [&](auto actfn) {
-        // hidden layers feed the next layer's A fragments -> chunk-transposed column; the output layer is read
-        // back by dimension -> plain column
-        const int j = apply_act ? lds_col(lane & 15) : (lane & 15);
-        const int g4 = 4 * (lane >> 4);
+        const int j = lane & 15, g4 = 4 * (lane >> 4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int col = (c_first + kWaves * ct) * 16 + j;
+            const int col = (c_first + kWaves * ct) * 16 + g4;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r) {
+                f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) out[(r * 16 + g4 + i) * ld + col] = actfn(acc[ct][r][i] + bv[ct]);
+                for (int i = 0; i < 4; ++i) v[i] = actfn(acc[ct][r][i] + bv[ct][i]);
+                *reinterpret_cast<f32x4*>(out + (r * 16 + j) * ld + col) = v;
+            }
         }
 #pragma unroll
         for (int e = 0; e < EX; ++e) {
-            const int col = exc[e] * 16 + j;
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(exr[e] * 16 + g4 + i) * ld + col] = actfn(accx[e][i] + bvx[e]);
+            for (int i = 0; i < 4; ++i) v[i] = actfn(accx[e][i] + bvx[e][i]);
+            *reinterpret_cast<f32x4*>(out + (exr[e] * 16 + j) * ld + exc[e] * 16 + g4) = v;
         }
     };
     if (!apply_act) {
@@ -834,10 +839,10 @@ __global__ void export_normals_kernel(float* out, int H, int B, int out_dim, uns
 }
 
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
-//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + (lane&15)]   (0 outside K x N)
+//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
 // so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
 __global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
-                                    int Np, long long member_stride, long long layer_off) {
+                                    int Np, long long member_stride, long long layer_off, int permute_cols) {
     const long long per_member = (long long)Kp * Np;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_member * M) return;
@@ -849,18 +854,21 @@ __global__ void pack_weights_kernel(float* dst, const float* src, const int* mem
     const int kk = (int)(r % KC);
     const int c = (int)(r / KC);
     const int k = 16 * kk + 4 * s + (lane >> 4);  // MFMA k-step s of a chunk covers k = 16 kk + 4 s + {0,1,2,3}
-    const int n = 16 * c + (lane & 15);
+    // fragment row (lane & 15) = index m of the transposed product D^T[m][batch row]; hidden layers map it to the
+    // real column lds_col(m) so that accumulator register i of lane group g lands on LDS position 4g + i
+    const int n = 16 * c + (permute_cols ? lds_col(lane & 15) : (lane & 15));
     float v = 0.f;
     if (k < K && n < N) v = src[((size_t)members[m] * K + k) * N + n];
     dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
 }
 
 __global__ void pack_bias_kernel(float* dst, const float* src, const int* members, int M, int N, int Np, int member_stride,
-                                 int layer_off) {
+                                 int layer_off, int permute_cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * Np) return;
-    const int m = i / Np, n = i % Np;
-    dst[(size_t)m * member_stride + layer_off + n] = n < N ? src[(size_t)members[m] * N + n] : 0.f;
+    const int m = i / Np, np_ = i % Np;
+    const int n = permute_cols ? lds_col(np_) : np_;  // same permutation as the weight columns
+    dst[(size_t)m * member_stride + layer_off + np_] = n < N ? src[(size_t)members[m] * N + n] : 0.f;
 }
 
 }  // namespace hipets
