@@ -160,24 +160,14 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
 
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) {
-#if defined(HIPETS_EXP) && (HIPETS_EXP & 1)
-        const int kb = 0;  // experiment: B fragments always from chunk 0 (L1 resident)
-#else
-        const int kb = kk;
-#endif
-#if defined(HIPETS_EXP) && (HIPETS_EXP & 2)
-        const int ka = 0;  // experiment: A fragments always from chunk 0
-#else
-        const int ka = kk;
-#endif
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(W + woff[ct] + kb * 256);
+        for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(W + woff[ct] + kk * 256);
 #pragma unroll
-        for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(W + wxoff[e] + kb * 256);
+        for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(W + wxoff[e] + kk * 256);
 #pragma unroll
-        for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + ka * 16);
+        for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + kk * 16);
 #pragma unroll
-        for (int e = 0; e < EX; ++e) f.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + ka * 16);
+        for (int e = 0; e < EX; ++e) f.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + kk * 16);
     };
     // Hazards the compiler cannot see inside asm: (1) a VALU write (e.g. a phi copy of an accumulator) must be
     // >= 2 wait states ahead of the MFMA that reads it -> s_nop 1 opens every k-step; (2) an MFMA that takes the
@@ -233,6 +223,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // scheduler sinks each load group down to its first use and the pipeline degenerates to load->wait->compute.
     GemmFrags<R, CT, EX> f0, f1;
     load(f0, 0);
+    prof.mark(14);
     const int last = KC - 1;
     int kk = 0;
     for (; kk + 2 < KC; kk += 2) {  // chunks kk, kk+1 are not the last one
@@ -325,9 +316,9 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 
 // One linear layer (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS).
 template <int R>
-__device__ __forceinline__ void mlp_layer(const ModelDev& md, const int l, const int member, const float* in,
-                                          float* out, const int wave, const int lane, Prof& prof) {
-    const LayerMeta lm = md.layers[l];
+__device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
+                                          const float* in, float* out, const int wave, const int lane, Prof& prof) {
+    const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
     const int KC = lm.Kp / kKChunk;
     const int C = lm.Np / kTile;
     const float* W = md.w + (size_t)member * md.wmember + lm.woff;
@@ -464,6 +455,7 @@ struct RolloutSmem {
     float* maxlv;    // [out_dim]
     int* nodelta;    // [obs_dim]
     int* sched;      // [H] member slot of this workgroup per step (FAST)
+    LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
@@ -480,6 +472,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += 2 * align16((size_t)out_dim * 4);
     n += align16((size_t)obs_dim * 4);
     n += align16((size_t)horizon * 4);
+    n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
@@ -508,6 +501,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         sm.maxlv = reinterpret_cast<float*>(p); p += align16((size_t)md.out_dim * 4);
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
+        sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
@@ -546,6 +540,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     if (!md.deterministic)
         for (int i = tid; i < md.out_dim; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
     for (int i = tid; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
+    for (int i = tid; i < md.n_layers; i += kThreads) sm.lmeta[i] = md.layers[i];
     __syncthreads();
 
     // ---- initial state ------------------------------------------------------------------------
@@ -664,7 +659,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             float* nxt = sm.buf1;
             for (int l = 0; l < md.n_layers; ++l) {
                 prof.mark(12);
-                mlp_layer<R>(md, l, member, cur, nxt, wave, lane, prof);
+                mlp_layer<R>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;

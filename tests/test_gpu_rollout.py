@@ -64,6 +64,8 @@ SIZES = [
     (17, 6, 500, 20, 30, dict(ensemble_size=5, hid=200)),  # cfg2 at BASELINE.json's full size
     (4, 1, 100, 5, 15, dict(ensemble_size=5, hid=200, reward="cartpole", termination="cartpole")),  # cfg1
     (45, 17, 35, 20, 6, dict(ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")),  # cfg4 shape
+    (45, 17, 1036, 20, 4, dict(ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")),  # cfg4 batch (iter 0)
+    (17, 6, 2000, 20, 5, dict(ensemble_size=5, hid=200)),  # cfg5 batch: 40 000 rows
     (17, 6, 1, 5, 3, dict(ensemble_size=5, hid=200)),  # single candidate
     (17, 6, 7, 5, 4, dict(ensemble_size=5, hid=33)),  # odd hidden width
     (17, 6, 48, 10, 3, dict(ensemble_size=2, hid=256, num_layers=2)),
@@ -84,7 +86,7 @@ def test_exact_mode_matches_oracle(engine, case):
     assert_returns_close(out, ref)
 
 
-@pytest.mark.parametrize("case", SIZES[:7], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+@pytest.mark.parametrize("case", SIZES[:9], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
 def test_fast_mode_replayed_through_oracle(engine, case):
     """FAST mode end to end (balanced member schedule + Philox eps drawn in-kernel): export the kernel's own
     randomness through the ABI, replay it through the oracle's explicit row->member form, compare returns."""
