@@ -20,6 +20,8 @@
 //               its rows for all H steps, state stays in LDS, the member is drawn per
 //               (workgroup, step) from a balanced schedule, eps comes from Philox.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace hipets {
@@ -159,7 +161,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
     for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
 
-    auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) {
+    auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(W + woff[ct] + kk * 256);
 #pragma unroll
@@ -175,7 +177,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // VGPR accumulators -> a wave whose whole share is ONE unit alternates two accumulators (even / odd k-steps).
     constexpr bool kSplit = (CT * R + EX) == 1;
     f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto kstep = [&](const GemmFrags<R, CT, EX>& f, const int s) {
+    auto kstep = [&](const GemmFrags<R, CT, EX>& f, const int s) __attribute__((always_inline)) {
         asm volatile("s_nop 1");
         if constexpr (kSplit) {
             f32x4& dst = (s & 1) ? acc_odd : (CT ? acc[0][0] : accx[0]);
@@ -190,7 +192,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
             for (int e = 0; e < EX; ++e) mfma16x16x4(f.bx[e][s], f.ax[e][s], accx[e]);
         }
     };
-    auto compute = [&](const GemmFrags<R, CT, EX>& f) {
+    auto compute = [&](const GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) kstep(f, s);
     };
@@ -199,7 +201,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // register before the matrix pipe has written it.  drain_all() = wait out the pipe, then re-define every
     // accumulator through an empty asm so such copies can only be scheduled after the wait.  It ends every
     // conditional arm below and follows the main loop; the loop body itself is branch-free and in place.
-    auto drain_all = [&]() {
+    auto drain_all = [&]() __attribute__((always_inline)) {
         mfma_drain();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -210,7 +212,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         asm volatile("" : "+v"(acc_odd));
     };
     // last chunk: only the k-steps that hold real (non-padding) weights, e.g. 2 of 4 for K = 200
-    auto compute_tail = [&](const GemmFrags<R, CT, EX>& f) {
+    auto compute_tail = [&](const GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {
         switch (tail_steps) {
             case 1: kstep(f, 0); drain_all(); break;
             case 2: kstep(f, 0); kstep(f, 1); drain_all(); break;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // accumulator holds 4 CONSECUTIVE LDS columns (16c + 4g .. +3; the weight / bias packing pre-permutes the real
     // columns so that this holds in the chunk-transposed layout too) of batch row 16r + (lane & 15): one
     // ds_write_b128 per accumulator instead of four ds_write_b32.
-    auto store = [&](auto actfn) {
+    auto store = [&](auto actfn) __attribute__((always_inline)) {
         const int j = lane & 15, g4 = 4 * (lane >> 4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             if (rid >= 0) act_base[q] = (long long)(rid / ra.P) * ra.H * md.act_dim + a;
         }
     }
-    auto fetch_actions_rest = [&](const int t) {  // elements beyond kPrefetch per thread (very wide action spaces)
+    auto fetch_actions_rest = [&](const int t) __attribute__((always_inline)) {  // elements beyond kPrefetch per thread (very wide action spaces)
         float* actn_t = sm.actn + (t & 1) * n_act;
         for (int i = tid + kPrefetch * kThreads; i < n_act; i += kThreads) {
             const int s = i / md.act_dim, a = i % md.act_dim;
@@ -609,7 +611,11 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0.
     // One item = (row, 4 consecutive columns): four independent LDS-read -> f64 normalise -> LDS-write chains.
     const int kq = Kp0 >> 2;  // column quads per row (Kp0 is a multiple of 16)
-    auto build_input = [&](const int t) {
+    // The (wave-uniform) normaliser / obs-preprocess switches are resolved ONCE per call into a compile-time variant:
+    // with the switches inside, each of the four elements became its own chain of scalar branches and waits.
+    auto build_input_impl = [&](const int t, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
+        constexpr int NORM = decltype(norm_tag)::value;
+        constexpr bool PLAIN = decltype(plain_tag)::value;
         const float* actn_t = sm.actn + (t & 1) * n_act;
         for (int i = tid; i < ROWS * kq; i += kThreads) {
             const int s = i / kq, cq = i % kq;
@@ -618,16 +624,39 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = 4 * cq + q;
-                v[q] = 0.f;
-                if (c < md.in_dim && valid) {
-                    v[q] = c < md.obs_in ? processed_obs(sm.state + s * md.obs_dim, c, md.obs_process)
-                                         : actn_t[s * md.act_dim + (c - md.obs_in)];
-                    if (md.normalizer == HIPETS_NORM_F64) v[q] = (float)(((double)v[q] - sm.nmean[c]) / sm.nstd[c]);
-                    else if (md.normalizer == HIPETS_NORM_F32) v[q] = (v[q] - (float)sm.nmean[c]) / (float)sm.nstd[c];
+                const int cc = min(c, md.in_dim - 1);  // clamped index: loads stay in bounds, result masked below
+                float x;
+                if (cc < md.obs_in) {
+                    if constexpr (PLAIN) x = sm.state[s * md.obs_dim + cc];
+                    else x = processed_obs(sm.state + s * md.obs_dim, cc, md.obs_process);
+                } else {
+                    x = actn_t[s * md.act_dim + (cc - md.obs_in)];
                 }
+                if constexpr (NORM == HIPETS_NORM_F64) x = (float)(((double)x - sm.nmean[cc]) / sm.nstd[cc]);
+                else if constexpr (NORM == HIPETS_NORM_F32) x = (x - (float)sm.nmean[cc]) / (float)sm.nstd[cc];
+                v[q] = (c < md.in_dim && valid) ? x : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) sm.buf0[s * md.ld + lds_col(4 * cq + q)] = v[q];
+        }
+    };
+    auto build_input = [&](const int t) __attribute__((always_inline)) {
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool plain = md.obs_process == HIPETS_OBS_NONE;
+        switch (md.normalizer) {
+            case HIPETS_NORM_F64:
+                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, T{});
+                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, F{});
+                break;
+            case HIPETS_NORM_F32:
+                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F32>{}, T{});
+                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F32>{}, F{});
+                break;
+            default:
+                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_NONE>{}, T{});
+                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_NONE>{}, F{});
+                break;
         }
     };
 
@@ -682,58 +711,77 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         }
 
         // ---- sample, delta, next obs (model.py:458-473, one_dim_tr_model.py:280-288) -----------
-        const bool sample = !md.deterministic && (ra.eps != nullptr || ra.use_philox != 0);
+        // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
+        // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
+        // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
         const bool more = t + 1 < ra.t_end;
         float av[kPrefetch];
         if (more) fetch_actions_issue(t + 1, av);  // HBM latency hides behind this phase
-        for (int item = tid; item < ROWS * nblk; item += kThreads) {
-            const int s = item / nblk, blk = item % nblk;
-            const int rid = sm.rowid[s];
-            if (rid < 0) continue;
-            float nrm[4] = {0.f, 0.f, 0.f, 0.f};
-            if (sample) {
-                if (ra.eps) {
+        auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
+            constexpr bool EXPECT = decltype(expect_tag)::value;
+            constexpr int MODE = decltype(mode_tag)::value;
+            const float inv_m = 1.0f / (float)md.M;
+            for (int item = tid; item < ROWS * nblk; item += kThreads) {
+                const int s = item / nblk, blk = item % nblk;
+                const int rid = sm.rowid[s];
+                if (rid < 0) continue;
+                float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int d = blk * 4 + q;
-                        if (d < md.out_dim) nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
+                        const int d = min(blk * 4 + q, md.out_dim - 1);
+                        nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
                     }
-                } else {
+                } else if constexpr (MODE == 2) {
                     rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
                 }
-            }
-            // straight-line over the 4 dims of the block (indices clamped, stores predicated) so the four
-            // dependent chains (LDS read -> 2 softplus -> exp -> sqrt -> fma) interleave
-            float pred[4], prev[4];
+                float pred[4], prev[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = min(blk * 4 + q, md.out_dim - 1);
-                float mean, lv = 0.f;
-                if (expectation) {
-                    mean = sm.expacc[s * md.out_total + d] / (float)md.M;
-                    if (!md.deterministic) lv = sm.expacc[s * md.out_total + md.out_dim + d] / (float)md.M;
-                } else {
-                    mean = result[s * md.ld + d];
-                    if (!md.deterministic) {
-                        lv = result[s * md.ld + md.out_dim + d];
-                        lv = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - lv);  // gaussian_mlp.py:152
-                        lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
+                for (int q = 0; q < 4; ++q) {
+                    const int d = min(blk * 4 + q, md.out_dim - 1);
+                    float mean, lv = 0.f;
+                    if constexpr (EXPECT) {
+                        mean = sm.expacc[s * md.out_total + d] / (float)md.M;
+                        if constexpr (MODE != 0) lv = sm.expacc[s * md.out_total + md.out_dim + d] / (float)md.M;
+                    } else {
+                        mean = result[s * md.ld + d];
+                        if constexpr (MODE != 0) {
+                            lv = result[s * md.ld + md.out_dim + d];
+                            lv = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - lv);  // gaussian_mlp.py:152
+                            lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
+                        }
+                    }
+                    if constexpr (MODE != 0) pred[q] = mean + __builtin_sqrtf(__expf(lv)) * nrm[q];  // model.py:471-473
+                    else pred[q] = mean;
+                    const int do_ = min(d, md.obs_dim - 1);
+                    prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
+                }
+                (void)inv_m;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int d = blk * 4 + q;
+                    if (d < md.obs_dim) {
+                        const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
+                        sm.state[s * md.obs_dim + d] = nobs;
+                        if (ra.trace_next_obs) ra.trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
+                    } else if (d < md.out_dim) {
+                        sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
                     }
                 }
-                pred[q] = sample ? mean + __builtin_sqrtf(__expf(lv)) * nrm[q] : mean;  // model.py:471-473
-                const int do_ = min(d, md.obs_dim - 1);
-                prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = blk * 4 + q;
-                if (d < md.obs_dim) {
-                    const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
-                    sm.state[s * md.obs_dim + d] = nobs;
-                    if (ra.trace_next_obs) ra.trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
-                } else if (d < md.out_dim) {
-                    sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
-                }
+        };
+        {
+            using T = std::true_type;
+            using F = std::false_type;
+            const int mode = md.deterministic ? 0 : (ra.eps != nullptr ? 1 : (ra.use_philox ? 2 : 0));
+            if (expectation) {
+                if (mode == 0) sample_impl(T{}, std::integral_constant<int, 0>{});
+                else if (mode == 1) sample_impl(T{}, std::integral_constant<int, 1>{});
+                else sample_impl(T{}, std::integral_constant<int, 2>{});
+            } else {
+                if (mode == 0) sample_impl(F{}, std::integral_constant<int, 0>{});
+                else if (mode == 1) sample_impl(F{}, std::integral_constant<int, 1>{});
+                else sample_impl(F{}, std::integral_constant<int, 2>{});
             }
         }
         if (more) fetch_actions_commit(t + 1, av);
