@@ -291,11 +291,11 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         store([](float x) { return x; });
     } else {
         switch (act) {
-            case HIPETS_ACT_SILU: store([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }); break;
+            case HIPETS_ACT_SILU: store([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }); break;
             case HIPETS_ACT_RELU: store([](float x) { return fmaxf(x, 0.0f); }); break;
             case HIPETS_ACT_LEAKY_RELU: store([slope](float x) { return x > 0.0f ? x : slope * x; }); break;
             case HIPETS_ACT_TANH: store([](float x) { return tanhf(x); }); break;
-            default: store([](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }); break;
+            default: store([](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }); break;
         }
     }
     prof.mark(13);
@@ -479,8 +479,14 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     return n;
 }
 
-// log(1 + e^x) with the hardware exp/log (abs error ~1e-7; F.softplus' threshold-20 branch kept)
-__device__ __forceinline__ float softplus_fast(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
+// Raw hardware transcendentals (v_exp_f32 / v_log_f32 are base 2, ~1 ulp, no denormal fix-up sequences).
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float log_hw(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+// log(1 + e^x) (abs error ~1e-7; F.softplus' threshold-20 branch kept as a select)
+__device__ __forceinline__ float softplus_fast(float x) {
+    const float y = log_hw(1.0f + exp_hw(fminf(x, 20.0f)));
+    return x > 20.0f ? x : y;
+}
 
 template <int R>
 __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                             lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
                         }
                     }
-                    if constexpr (MODE != 0) pred[q] = mean + __builtin_sqrtf(__expf(lv)) * nrm[q];  // model.py:471-473
+                    if constexpr (MODE != 0) pred[q] = mean + __builtin_amdgcn_sqrtf(exp_hw(lv)) * nrm[q];  // model.py:471-473
                     else pred[q] = mean;
                     const int do_ = min(d, md.obs_dim - 1);
                     prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
