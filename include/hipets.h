@@ -106,6 +106,7 @@ typedef struct {
     int32_t rows_per_group;  /* 0 = auto; else force R (row tiles of 16 per workgroup)            */
     int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
                              /*   workgroup 0, accumulated (profiling aid)                */
+    int32_t no_sample;       /* FAST: predictions are the mean (no eps), like ModelEnv.step(sample=False) */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -122,6 +123,15 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* desc, void* stre
 /* actions DEVICE [pop,H,A] f32; s0 HOST [obs_dim] f32; returns DEVICE [pop] f32.              */
 int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t horizon,
                    int32_t num_particles, const hipets_rollout_opts* opts, float* returns, void* stream);
+/* ---- ModelEnv.step (mbrl/models/model_env.py:87-140; MBPO-style one-step model rollouts) ---
+ * One transition for B independent rows: obs DEVICE [B,obs_dim], actions DEVICE [B,act_dim] ->
+ * next_obs DEVICE [B,obs_dim], rewards DEVICE [B] f32, dones DEVICE [B] uint8.  opts as for hipets_rollout with
+ * horizon 1 and one particle per row: EXACT takes perms [B] (one torch.randperm, or the fixed_model indices) and eps
+ * [1,B,out_dim] (NULL => the deterministic mean, i.e. ModelEnv.step(sample=False)); FAST draws both in-kernel from
+ * (seed, stream_id); set opts->no_sample for the deterministic mean in FAST mode.                                  */
+int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t batch, const hipets_rollout_opts* opts,
+                float* next_obs, float* rewards, uint8_t* dones, void* stream);
+
 /* geometry the FAST kernel will use for (pop, P): workgroups and rows per group (for member_schedule) */
 int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t rows_per_group,
                          int32_t* n_workgroups, int32_t* row_tiles);

@@ -418,7 +418,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d); shard the population", nwg);
         ra.groups = groups;
         ra.eps = o->fast_eps;
-        ra.use_philox = o->fast_eps ? 0 : 1;
+        ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
         if (md.propagation != HIPETS_PROP_EXPECTATION) {
             if (o->member_schedule) {
                 ra.schedule = o->member_schedule;
@@ -439,6 +439,84 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     }
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t B, const hipets_rollout_opts* o, float* next_obs,
+                float* rewards, uint8_t* dones, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (!obs || !actions || !o || !next_obs || !rewards || !dones) return fail("null argument");
+    if (B < 1) return fail("bad batch");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const ModelDev& md = e->md;
+    if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
+    if (B % md.M != 0)  // gaussian_mlp.py:195-200
+        return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
+                    "Current batch size is %d for %d models.", B, md.M);
+    // the kernel updates state / totals / terminated in place: run it on the caller's output buffers
+    HCHECK(hipMemcpyAsync(next_obs, obs, (size_t)B * md.obs_dim * 4, hipMemcpyDeviceToDevice, st));
+    HCHECK(hipMemsetAsync(rewards, 0, (size_t)B * 4, st));
+    HCHECK(hipMemsetAsync(dones, 0, (size_t)B, st));
+    RolloutArgs ra{};
+    ra.pop = B; ra.P = 1; ra.H = 1; ra.B = B;
+    ra.mode = o->mode;
+    ra.actions = actions;
+    ra.s0 = nullptr;
+    ra.state = next_obs;
+    ra.totals = rewards;
+    ra.term = dones;
+    ra.seed = o->seed;
+    ra.stream_id = o->stream_id;
+    ra.trace_next_obs = nullptr;
+    ra.trace_rewards = nullptr;
+    ra.phase_cycles = nullptr;
+    ra.t_begin = 0;
+    ra.t_end = 1;
+    if (o->mode == HIPETS_MODE_EXACT) {
+        const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
+        const int domains = expectation ? 1 : md.M;
+        if (!expectation && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
+        const int rpd = B / domains;
+        const long long tiles = (rpd + kTile - 1) / kTile;
+        const int R = choose_R(e, tiles, domains, o->rows_per_group, 1);
+        const size_t lds = lds_for(e, R, 1);
+        if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+        ra.groups = (int)((tiles + R - 1) / R);
+        ra.rows_per_domain = rpd;
+        ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
+        ra.perm_step = 0;
+        ra.eps = o->eps;
+        ra.use_philox = 0;
+        if (launch_rollout(e, R, domains * ra.groups, lds, ra, st)) return 1;
+    } else if (o->mode == HIPETS_MODE_FAST) {
+        const long long tiles = (B + kTile - 1) / kTile;
+        const int R = choose_R(e, tiles, 1, o->rows_per_group, 1);
+        const size_t lds = lds_for(e, R, 1);
+        if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+        const int nwg = (int)((tiles + R - 1) / R);
+        if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d)", nwg);
+        ra.groups = nwg;
+        ra.eps = o->fast_eps;
+        ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
+        ra.init_states = next_obs;
+        ra.write_back = 1;
+        if (md.propagation != HIPETS_PROP_EXPECTATION) {
+            if (o->member_schedule) {
+                ra.schedule = o->member_schedule;
+            } else {
+                if (e->schedule.ensure((size_t)nwg * 4)) return 1;
+                hipLaunchKernelGGL(member_schedule_kernel, dim3(1), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
+                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)o->seed,
+                                   (unsigned long long)o->stream_id);
+                HCHECK(hipGetLastError());
+                ra.schedule = e->schedule.as<int>();
+            }
+        }
+        if (launch_rollout(e, R, nwg, lds, ra, st)) return 1;
+    } else {
+        return fail("unknown rollout mode %d", o->mode);
+    }
     return 0;
 }
 

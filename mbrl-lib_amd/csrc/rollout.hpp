@@ -78,6 +78,8 @@ struct RolloutArgs {
     float* trace_next_obs;
     float* trace_rewards;
     long long* phase_cycles;  // optional [kWaves][16 phases] cycle counters of workgroup 0 (profiling aid)
+    const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
+    int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
 };
 
 // D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         const int s = i / md.obs_dim, d = i % md.obs_dim;
         const int rid = sm.rowid[s];
         float v = 0.f;
-        if (fast) v = ra.s0[d];
+        if (fast) v = ra.init_states ? (rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f) : ra.s0[d];
         else if (rid >= 0) v = ra.state[(size_t)rid * md.obs_dim + d];
         sm.state[i] = v;
     }
@@ -818,9 +820,9 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         const int rid = sm.rowid[s];
         if (rid < 0) continue;
         ra.totals[rid] = sm.tot[s];
-        if (!fast) ra.term[rid] = (unsigned char)sm.term[s];
+        if (!fast || ra.write_back) ra.term[rid] = (unsigned char)sm.term[s];
     }
-    if (!fast) {
+    if (!fast || ra.write_back) {
         for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
             const int s = i / md.obs_dim, d = i % md.obs_dim;
             const int rid = sm.rowid[s];

@@ -5,7 +5,7 @@ Public names follow mbrl-lib so the stock Hydra configs only swap ``_target_``:
 ``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))``.
 """
 from ._lib import HipetsError, LIB_PATH  # noqa: F401
-from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_model_env  # noqa: F401
+from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_checkpoint, spec_from_model_env  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .planning import (  # noqa: F401
     Agent,
@@ -13,6 +13,7 @@ from .planning import (  # noqa: F401
     HipTrajectoryEvalFn,
     ICEMOptimizer,
     MPPIOptimizer,
+    ModelEnv,
     Optimizer,
     TrajectoryOptimizer,
     TrajectoryOptimizerAgent,

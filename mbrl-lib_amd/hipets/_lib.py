@@ -44,6 +44,7 @@ class RolloutOpts(C.Structure):
         ("trace_next_obs", C.c_void_p), ("trace_rewards", C.c_void_p),
         ("rows_per_group", C.c_int32),
         ("phase_cycles", C.c_void_p),
+        ("no_sample", C.c_int32),
     ]
 
 
@@ -64,6 +65,7 @@ SYMBOLS = {
     "hipets_destroy": (None, [_P]),
     "hipets_set_model": (C.c_int, [_P, C.POINTER(ModelDesc), _P]),
     "hipets_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RolloutOpts), _P, _P]),
+    "hipets_step": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RolloutOpts), _P, _P, _P, _P]),
     "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_fast_schedule": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),

@@ -165,6 +165,46 @@ class Engine:
                                                 num_particles, C.byref(o), _ptr(out), _stream(dev)))
         return out
 
+    def step(self, obs: torch.Tensor, actions: torch.Tensor, *, mode: str = "fast", sample: bool = True,
+             perm: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, seed: int = 0, stream_id: int = 0,
+             member_schedule: Optional[torch.Tensor] = None, rows_per_group: int = 0):
+        """One model transition for B independent rows (ModelEnv.step, mbrl/models/model_env.py:87-140).
+        Returns (next_obs [B,obs], rewards [B,1], dones [B,1] bool) on the device."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        B = int(obs.shape[0])
+        _check_dev(obs, torch.float32, dev, "obs", (B, self.spec.obs_dim))
+        _check_dev(actions, torch.float32, dev, "actions", (B, self.spec.act_dim))
+        o = RolloutOpts()
+        o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
+        o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
+        o.rows_per_group = int(rows_per_group)
+        o.no_sample = int(not sample)
+        if mode == "exact":
+            if perm is not None:
+                _check_dev(perm, torch.int64, dev, "perm", (B,))
+                o.perms = _ptr(perm)
+            if sample and not self.spec.deterministic:
+                if eps is None:
+                    raise ValueError("EXACT step with sample=True needs eps [B, out_dim]")
+                _check_dev(eps, torch.float32, dev, "eps", numel=B * self.spec.out_dim)
+                o.eps = _ptr(eps)
+        else:
+            if eps is not None:
+                _check_dev(eps, torch.float32, dev, "eps", numel=B * self.spec.out_dim)
+                o.fast_eps = _ptr(eps)
+            if member_schedule is not None:
+                _check_dev(member_schedule, torch.int32, dev, "member_schedule")
+                o.member_schedule = _ptr(member_schedule)
+        next_obs = torch.empty_like(obs)
+        rewards = torch.empty(B, dtype=torch.float32, device=dev)
+        dones = torch.empty(B, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_step(self._h, _ptr(obs), _ptr(actions), B, C.byref(o), _ptr(next_obs), _ptr(rewards),
+                                             _ptr(dones), _stream(dev)))
+        return next_obs, rewards.view(B, 1), dones.view(B, 1).bool()
+
     def fast_geometry(self, pop: int, num_particles: int, horizon: int, rows_per_group: int = 0):
         nwg, r = C.c_int32(), C.c_int32()
         _lib.check(self._lib.hipets_fast_geometry(self._h, pop, num_particles, horizon, rows_per_group, C.byref(nwg),

@@ -13,6 +13,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 
 
@@ -174,3 +175,45 @@ def model_version(model_env) -> tuple:
     nid = (id(norm.mean), id(norm.std)) if norm is not None else ()
     el = tuple(mlp.elite_models) if getattr(mlp, "elite_models", None) is not None else None
     return (vers, nid, el, getattr(mlp, "propagation_method", None))
+
+
+def spec_from_checkpoint(model_dir, obs_dim: int, act_dim: int, **spec_kwargs) -> ModelSpec:
+    """Build a ModelSpec straight from a saved PETS run, without constructing any mbrl object:
+
+    * ``model.pth``        = ``{"state_dict", "elite_models"}`` written by ``GaussianMLP.save``
+      (mbrl/models/gaussian_mlp.py:381-387; keys ``hidden_layers.<i>.0.weight|bias``,
+      ``mean_and_logvar.weight|bias``, ``min_logvar``, ``max_logvar``)
+    * ``env_stats.pickle`` = ``{"mean", "std"}`` numpy arrays written by ``Normalizer.save``
+      (mbrl/util/math.py:168-174); absent => no input normaliser.
+
+    Everything a checkpoint does not record (activation, propagation, reward / termination fns, delta targets ...) comes
+    from ``spec_kwargs`` with the ModelSpec defaults (SiLU, TS1, delta targets, halfcheetah reward)."""
+    import os
+    import pickle
+
+    blob = torch.load(os.path.join(str(model_dir), "model.pth"), map_location="cpu", weights_only=False)
+    sd = blob["state_dict"]
+    ws, bs = [], []
+    i = 0
+    while f"hidden_layers.{i}.0.weight" in sd:
+        ws.append(sd[f"hidden_layers.{i}.0.weight"])
+        bs.append(sd[f"hidden_layers.{i}.0.bias"])
+        i += 1
+    if not ws or "mean_and_logvar.weight" not in sd:
+        raise UnsupportedModelError("model.pth does not hold a GaussianMLP state dict")
+    ws.append(sd["mean_and_logvar.weight"])
+    bs.append(sd["mean_and_logvar.bias"])
+    deterministic = "min_logvar" not in sd
+    kw = dict(spec_kwargs)
+    stats_path = os.path.join(str(model_dir), "env_stats.pickle")
+    if os.path.exists(stats_path):
+        with open(stats_path, "rb") as f:
+            stats = pickle.load(f)
+        kw.setdefault("norm_mean", torch.from_numpy(np.asarray(stats["mean"])))
+        kw.setdefault("norm_std", torch.from_numpy(np.asarray(stats["std"])))
+    elite = blob.get("elite_models")
+    spec = ModelSpec(weights=ws, biases=bs, obs_dim=obs_dim, act_dim=act_dim,
+                     min_logvar=None if deterministic else sd["min_logvar"], max_logvar=None if deterministic else sd["max_logvar"],
+                     elite_models=list(elite) if elite is not None else None, deterministic=deterministic, **kw)
+    spec.validate()
+    return spec

@@ -136,6 +136,80 @@ class HipTrajectoryEvalFn:
         return self._own_rng
 
 
+class ModelEnv:
+    """The model-as-environment interface of mbrl/models/model_env.py:15-191 on the fused kernels:
+    ``reset`` / ``step`` (one transition for a batch of independent rows: what MBPO-style model rollouts and the
+    visualisers call) and ``evaluate_action_sequences``.  Built from a ``ModelSpec`` or a live mbrl ``ModelEnv``."""
+
+    def __init__(self, model, engine: Optional[Engine] = None, mode: str = "fast", seed: int = 0, device=None,
+                 generator: Optional[torch.Generator] = None):
+        self._eval = HipTrajectoryEvalFn(model, 1, engine=engine, mode=mode, seed=seed, device=device, rng=generator)
+        self.engine, self.device, self.mode, self.seed = self._eval.engine, self._eval.device, mode, int(seed)
+        self._return_as_np = True
+        self._steps = 0
+        self._fixed_perm = None
+        self._fixed_schedule = None
+
+    @property
+    def spec(self) -> ModelSpec:
+        return self._eval.spec
+
+    def reset(self, initial_obs_batch: np.ndarray, return_as_np: bool = True) -> Dict[str, torch.Tensor]:
+        """model_env.py:62-85: returns the model state {"obs", "propagation_indices"}."""
+        assert len(initial_obs_batch.shape) == 2  # batch, obs_dim
+        self._eval.refresh()
+        obs = torch.as_tensor(np.asarray(initial_obs_batch, dtype=np.float32)).to(self.device).contiguous()
+        self._return_as_np = return_as_np
+        B = obs.shape[0]
+        self._eval.num_particles = 1
+        self._eval.check_batch(B)
+        self._fixed_perm = self._fixed_schedule = None
+        if self.spec.propagation == "fixed_model":  # model.py:404-407 -> gaussian_mlp.py:363-375
+            if self.mode == "exact":
+                self._fixed_perm = torch.randperm(B).to(self.device)
+            else:
+                tiles = -(-B // 16)
+                nwg, _ = self.engine.fast_geometry(B, 1, 1)
+                self._fixed_schedule = self.engine.fast_schedule(1, nwg, self.seed, self._steps + 1).contiguous()
+                del tiles
+        return {"obs": obs, "propagation_indices": self._fixed_perm}
+
+    def step(self, actions, model_state: Dict[str, torch.Tensor], sample: bool = False):
+        """model_env.py:87-140: (next_observs, rewards, dones, next_model_state)."""
+        assert len(actions.shape) == 2  # batch, action_dim
+        self._eval.refresh()
+        if self.engine.spec is not self.spec:
+            self.engine.set_model(self.spec)
+        if isinstance(actions, np.ndarray):
+            actions = torch.from_numpy(actions)
+        actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        obs = model_state["obs"].to(device=self.device, dtype=torch.float32).contiguous()
+        B = obs.shape[0]
+        self._steps += 1
+        if self.mode == "exact":
+            perm = eps = None
+            if self.spec.propagation == "random_model":
+                perm = torch.randperm(B).to(self.device)  # gaussian_mlp.py:205 (global RNG)
+            elif self.spec.propagation == "fixed_model":
+                perm = self._fixed_perm
+            if sample and not self.spec.deterministic:
+                eps = torch.empty(B, self.spec.out_dim).normal_(0.0, 1.0, generator=self._eval._cpu_rng()).to(self.device)
+            nobs, rew, done = self.engine.step(obs, actions, mode="exact", sample=sample, perm=perm, eps=eps)
+        else:
+            nobs, rew, done = self.engine.step(obs, actions, mode="fast", sample=sample, seed=self.seed, stream_id=self._steps,
+                                               member_schedule=self._fixed_schedule)
+        next_state = {"obs": nobs, "propagation_indices": model_state.get("propagation_indices")}
+        if self._return_as_np:
+            return nobs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), next_state
+        return nobs, rew, done, next_state
+
+    def evaluate_action_sequences(self, action_sequences: torch.Tensor, initial_state: np.ndarray, num_particles: int) -> torch.Tensor:
+        """model_env.py:145-191."""
+        assert len(action_sequences.shape) == 3
+        self._eval.num_particles = int(num_particles)
+        return self._eval(initial_state, action_sequences)
+
+
 def make_eval_fn(model, num_particles: int, **kw) -> HipTrajectoryEvalFn:
     """``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))`` on a stock or a
     hipets agent (seam 3 of SURVEY.md section 8b)."""

@@ -274,6 +274,33 @@ def model_input(m: OracleModel, obs: torch.Tensor, act: torch.Tensor) -> torch.T
 
 
 # ----------------------------------------------------------------------------------------
+# ModelEnv.step  (models/model_env.py:87-140) -> OneDTransitionRewardModel.sample (one_dim_tr_model.py:245-289)
+# ----------------------------------------------------------------------------------------
+
+
+def step(m: OracleModel, x: torch.Tensor, a: torch.Tensor, perm: Optional[torch.Tensor] = None,
+         eps: Optional[torch.Tensor] = None, member_of_row: Optional[torch.Tensor] = None, sample: bool = True):
+    """One transition for a batch: returns (next_obs [B,obs], rewards [B,1], dones [B,1] bool).
+    ``sample=False`` is ModelEnv.step's default (deterministic mean, model.py:458-466)."""
+    inp = model_input(m, x, a)
+    mean, logvar = ensemble_forward(m, inp, perm, member_of_row)
+    if m.deterministic or logvar is None or not sample:
+        pred = mean
+    else:
+        pred = mean + torch.sqrt(logvar.exp()) * eps  # model.py:471-473
+    nobs = pred[:, :-1] if m.learned_rewards else pred
+    if m.target_is_delta:
+        tmp = nobs + x
+        for d in m.no_delta_list:
+            tmp[:, d] = nobs[:, d]
+        nobs = tmp
+    rew_fn = REWARD_FNS[m.reward] if m.reward is not None else None
+    r = pred[:, -1:].clone() if rew_fn is None else rew_fn(a, nobs)
+    d = TERMINATION_FNS[m.termination](a, nobs)
+    return nobs, r, d
+
+
+# ----------------------------------------------------------------------------------------
 # ModelEnv.evaluate_action_sequences  (models/model_env.py:145-191)
 # ----------------------------------------------------------------------------------------
 

@@ -222,3 +222,53 @@ def test_weights_resnapshot_after_training_step(engine):
     b = engine.rollout(actions.to(DEV), s0, 5, mode="exact", perms=perms.to(DEV), eps=eps.to(DEV))
     assert not torch.allclose(a, b)
     assert_returns_close(b, po.rollout(om, actions, s0, 5, perms=perms, eps=eps))
+
+
+@pytest.mark.parametrize("sample", [False, True])
+@pytest.mark.parametrize("prop", ["random_model", "fixed_model", "expectation"])
+def test_step_exact_matches_oracle(engine, prop, sample):
+    """hipets_step (ModelEnv.step, model_env.py:87-140): per-row initial states, one transition."""
+    obs, act, B = 11, 3, 120
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=40, seed=9, termination="hopper", no_delta_list=[1], propagation=prop)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, obs, generator=g) * 0.3
+    x[:, 0] += 0.75
+    a = torch.rand(B, act, generator=g) * 2 - 1
+    perm = None if prop == "expectation" else torch.randperm(B, generator=g)
+    eps = torch.randn(B, obs, generator=g) if sample else None
+    rn, rr, rd = po.step(om, x, a, perm=perm, eps=eps, sample=sample)
+    nobs, rew, done = engine.step(x.to(DEV), a.to(DEV), mode="exact", sample=sample, perm=None if perm is None else perm.to(DEV),
+                                  eps=None if eps is None else eps.to(DEV))
+    assert torch.allclose(nobs.cpu(), rn, rtol=1e-5, atol=2e-6)
+    assert torch.allclose(rew.cpu(), rr, rtol=1e-5, atol=2e-6)
+    assert torch.equal(done.cpu(), rd) and 0 < int(rd.sum()) < B  # a mix of terminated / alive rows
+
+
+def test_model_env_class_reset_step_fast_mode_replayed(engine):
+    """hipets.ModelEnv.reset/step in FAST mode, replayed through the oracle with the exported schedule and normals."""
+    import hipets
+
+    obs, act, B = 17, 6, 100
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=32, seed=3)
+    env = hipets.ModelEnv(to_spec(om, obs, act), engine=engine, mode="fast", seed=11)
+    g = torch.Generator().manual_seed(0)
+    obs0 = (torch.randn(B, obs, generator=g) * 0.2).numpy()
+    a = torch.rand(B, act, generator=g) * 2 - 1
+    state = env.reset(obs0, return_as_np=False)
+    n1, r1, d1, state = env.step(a.to(DEV), state, sample=True)
+    nwg, r = engine.fast_geometry(B, 1, 1)
+    sched = engine.fast_schedule(1, nwg, 11, 1).cpu()[0]
+    eps = engine.fast_normals(1, B, 11, 1).cpu()[0]
+    members = sched[torch.arange(B) // (16 * r)].long()
+    rn, rr, rd = po.step(om, torch.from_numpy(obs0.astype(np.float32)), a, member_of_row=members, eps=eps, sample=True)
+    assert torch.allclose(n1.cpu(), rn, rtol=1e-5, atol=2e-6) and torch.allclose(r1.cpu(), rr, rtol=1e-5, atol=2e-6)
+    n2, _, _, _ = env.step(a.to(DEV), state, sample=False)  # deterministic mean
+    assert torch.isfinite(n2).all() and not torch.equal(n2, n1)
+    nnp = env.reset(obs0)  # return_as_np=True default like the reference
+    out = env.step(a.numpy(), nnp)
+    assert isinstance(out[0], np.ndarray) and out[1].shape == (B, 1) and out[2].dtype == bool
+    with pytest.raises(ValueError, match="multiple of the number of models"):
+        env.reset(obs0[:7])
+    vals = env.evaluate_action_sequences(torch.zeros(10, 4, act, device=DEV), obs0[0], 5)
+    assert vals.shape == (10,)

@@ -136,3 +136,22 @@ def test_shard_bounds_cover_population():
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
     assert [b - a for a, b in (hdist.shard_bounds(500, 8, r) for r in range(8))] == [63, 63, 63, 63, 62, 62, 62, 62]
+
+
+def test_spec_from_checkpoint_files(tmp_path):
+    """model.pth + env_stats.pickle in the reference's on-disk format (gaussian_mlp.py:381-387, util/math.py:168-174)."""
+    import pickle
+
+    s = small_spec()
+    sd = {}
+    for i, (w, b) in enumerate(zip(s.weights[:-1], s.biases[:-1])):
+        sd[f"hidden_layers.{i}.0.weight"], sd[f"hidden_layers.{i}.0.bias"] = w + i, b
+    sd["mean_and_logvar.weight"], sd["mean_and_logvar.bias"] = s.weights[-1], s.biases[-1]
+    sd["min_logvar"], sd["max_logvar"] = s.min_logvar, s.max_logvar
+    torch.save({"state_dict": sd, "elite_models": [2, 0]}, tmp_path / "model.pth")
+    with open(tmp_path / "env_stats.pickle", "wb") as f:
+        pickle.dump({"mean": np.full((1, 7), 0.5), "std": np.full((1, 7), 2.0)}, f)
+    spec = hipets.spec_from_checkpoint(tmp_path, obs_dim=5, act_dim=2, termination="hopper")
+    assert spec.members == [2, 0] and spec.termination == "hopper" and not spec.deterministic
+    assert spec.norm_mean.dtype == torch.float64 and float(spec.norm_std[0, 0]) == 2.0
+    assert len(spec.weights) == 3 and torch.equal(spec.weights[1], s.weights[1] + 1)

@@ -197,3 +197,45 @@ def test_spec_extraction_from_live_reference_objects(mbrl):
     assert hipets.model_version(me) != v0
     model.set_elite([0, 1, 2, 3, 4])
     assert hipets.spec_from_model_env(me).members == [0, 1, 2, 3, 4]
+
+
+def test_spec_from_checkpoint_written_by_the_reference(mbrl, tmp_path):
+    """A checkpoint saved by the real OneDTransitionRewardModel.save loads into the same ModelSpec as the live objects."""
+    import hipets
+
+    om = po.make_synthetic_model(17, 6, ensemble_size=7, hid=16, seed=0, elite=[0, 1, 3, 4, 6])
+    me, dm, model = build_reference_model_env(om, 17, 6, generator=torch.Generator())
+    dm.save(str(tmp_path))
+    live = hipets.spec_from_model_env(me)
+    disk = hipets.spec_from_checkpoint(tmp_path, 17, 6)
+    assert disk.members == live.members and disk.in_dim == live.in_dim
+    for a, b in zip(disk.weights + disk.biases, live.weights + live.biases):
+        assert torch.equal(a, b)
+    assert torch.equal(disk.norm_mean, live.norm_mean) and disk.norm_mean.dtype == torch.float64
+    assert torch.equal(disk.min_logvar, live.min_logvar)
+
+
+@pytest.mark.parametrize("sample", [False, True])
+def test_oracle_step_bitwise_vs_reference_model_env_step(mbrl, sample):
+    """ModelEnv.reset/step (model_env.py:62-140), the MBPO-style one-transition path."""
+    om = po.make_synthetic_model(11, 3, ensemble_size=5, hid=24, seed=7, termination="hopper", no_delta_list=[1])
+    me, _, _ = build_reference_model_env(om, 11, 3, generator=torch.Generator().manual_seed(2))
+    g = torch.Generator().manual_seed(0)
+    obs0 = (torch.randn(40, 11, generator=g) * 0.3).numpy()
+    obs0[:, 0] += 1.0
+    act = torch.rand(40, 3, generator=g) * 2 - 1
+    torch.manual_seed(5)
+    state = me.reset(obs0, return_as_np=False)
+    n1, r1, d1, state = me.step(act, state, sample=sample)
+    n2, r2, d2, _ = me.step(act, state, sample=sample)
+    torch.manual_seed(5)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.from_numpy(obs0.astype(np.float32))
+    outs = []
+    for _ in range(2):
+        perm = torch.randperm(40)
+        eps = torch.empty(40, 11).normal_(0, 1, generator=gen) if sample else None
+        x, r, d = po.step(om, x, act, perm=perm, eps=eps, sample=sample)
+        outs.append((x, r, d))
+    assert torch.equal(n1, outs[0][0]) and torch.equal(r1, outs[0][1]) and torch.equal(d1, outs[0][2])
+    assert torch.equal(n2, outs[1][0]) and torch.equal(r2, outs[1][1]) and torch.equal(d2, outs[1][2])
