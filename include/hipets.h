@@ -107,6 +107,8 @@ typedef struct {
     int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
                              /*   workgroup 0, accumulated (profiling aid)                */
     int32_t no_sample;       /* FAST: predictions are the mean (no eps), like ModelEnv.step(sample=False) */
+    int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
+                             /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -205,6 +207,12 @@ int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t horizon, int32_t a
 int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower,
                     const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
                     float* out, void* stream);
+/* The same for n_env independent environments in ONE set of launches (vectorised envs / many agents): x0 and out
+ * DEVICE [n_env,H,A], s0 HOST [n_env,obs_dim], bounds shared.  p->population_size is PER environment.  Fills all 256 CUs
+ * where a single plan cannot (cfg2 has 2.4 row tiles per CU).                                                    */
+int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_t n_env, const float* x0, const float* lower,
+                            const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
+                            float* out, void* stream);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 /* When enabled, every rollout-kernel launch is bracketed by hipEvents on `stream`.              */

@@ -9,7 +9,8 @@
 namespace hipets {
 
 struct CemDev {
-    int pop, H, A, D;  // D = H*A
+    int n_env;         // independent optimisation problems batched in one launch (mu / dispersion / best per env)
+    int pop, H, A, D;  // per-env population; D = H*A
     int K;             // elite_num
     float alpha, one_minus_alpha;
     int return_mean, clipped, unbiased;
@@ -46,9 +47,10 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
                                   const float* __restrict__ z_in, unsigned long long seed, unsigned long long stream,
                                   float* __restrict__ population) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)p.pop * p.D) return;
+    if (i >= (long long)p.n_env * p.pop * p.D) return;
     const int d = (int)(i % p.D);
-    const float m = mu[d], v = disp[d], lb = lower[d], ub = upper[d];
+    const int env = (int)(i / ((long long)p.pop * p.D));
+    const float m = mu[env * p.D + d], v = disp[env * p.D + d], lb = lower[d], ub = upper[d];
     float x;
     if (p.clipped) {  // :116-120
         const float z = z_in ? z_in[i] : philox_normal((uint32_t)i, (uint32_t)(i >> 32), seed, stream);
@@ -71,11 +73,20 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
 constexpr int kRefitThreads = 1024;
 constexpr int kMaxPop = 8192;
 
-__global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* __restrict__ values,
-                                                                 const float* __restrict__ population, float* __restrict__ mu,
-                                                                 float* __restrict__ disp, float* __restrict__ best_value,
-                                                                 float* __restrict__ best_solution, int* __restrict__ elite_idx_out) {
+__global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* values, const float* population, float* mu,
+                                                                 float* disp, float* best_value, float* best_solution,
+                                                                 int* elite_idx_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {  // one workgroup per environment: rebase every pointer to this environment's slice
+        const int env = blockIdx.x;
+        values += (size_t)env * p.pop;
+        population += (size_t)env * p.pop * p.D;
+        mu += (size_t)env * p.D;
+        disp += (size_t)env * p.D;
+        best_value += env;
+        best_solution += (size_t)env * p.D;
+        if (elite_idx_out) elite_idx_out += (size_t)env * p.K;
+    }
     int n2 = 1;
     while (n2 < p.pop) n2 <<= 1;
     float* key = reinterpret_cast<float*>(smem);
@@ -146,13 +157,14 @@ __global__ void fill_kernel(float* p, float v, int n) {
 // trajectory_opt.py:103-108: dispersion0 = ones (clipped) or ((ub - lb)^2) / 16; mu0 = x0
 __global__ void cem_init_kernel(const CemDev p, const float* x0, const float* lower, const float* upper, float* mu,
                                 float* disp, float* best_value) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < p.D) {
-        mu[d] = x0[d];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.n_env * p.D) {
+        const int d = i % p.D;
+        mu[i] = x0[i];
         const float w = upper[d] - lower[d];
-        disp[d] = p.clipped ? 1.0f : (w * w) / 16.0f;
+        disp[i] = p.clipped ? 1.0f : (w * w) / 16.0f;
     }
-    if (d == 0) best_value[0] = -INFINITY;
+    if (i < p.n_env) best_value[i] = -INFINITY;
 }
 
 }  // namespace hipets

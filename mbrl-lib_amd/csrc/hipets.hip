@@ -155,8 +155,9 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
     return best;
 }
 
-CemDev make_cem(const hipets_cem_params* p) {
+CemDev make_cem(const hipets_cem_params* p, int n_env = 1) {
     CemDev c{};
+    c.n_env = n_env;
     c.pop = p->population_size;
     c.H = p->horizon;
     c.A = p->act_dim;
@@ -359,9 +360,12 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     if (B > 0x7FFFFFFF / std::max(md.obs_dim, md.out_dim)) return fail("batch too large");
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
 
-    if (e->s0.ensure((size_t)md.obs_dim * 4)) return 1;
+    const int n_env = o->n_env > 1 ? o->n_env : 1;
+    if (n_env > 1 && (o->mode != HIPETS_MODE_FAST || pop % n_env != 0))
+        return fail("n_env %d needs FAST mode and a population (%d) divisible by it", n_env, pop);
+    if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
     if (e->totals.ensure((size_t)B * 4)) return 1;
-    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
 
     RolloutArgs ra{};
     ra.pop = pop; ra.P = P; ra.H = H; ra.B = (int)B;
@@ -374,6 +378,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     ra.trace_next_obs = o->trace_next_obs;
     ra.trace_rewards = o->trace_rewards;
     ra.phase_cycles = reinterpret_cast<long long*>(o->phase_cycles);
+    ra.pop_env = n_env > 1 ? pop / n_env : 0;
 
     if (o->mode == HIPETS_MODE_EXACT) {
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
@@ -638,35 +643,49 @@ int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t H, int32_t A, cons
 
 int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
                     const float* s0, int32_t P, uint64_t seed, uint64_t plan_id, float* out, void* stream) {
+    return hipets_plan_cem_batched(e, p, 1, x0, lower, upper, s0, P, seed, plan_id, out, stream);
+}
+
+int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_t n_env, const float* x0, const float* lower,
+                            const float* upper, const float* s0, int32_t P, uint64_t seed, uint64_t plan_id, float* out,
+                            void* stream) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (check_cem(p)) return 1;
     if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
+    if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    const CemDev c = make_cem(p);
-    if (e->mu.ensure((size_t)c.D * 4) || e->disp.ensure((size_t)c.D * 4) || e->best_solution.ensure((size_t)c.D * 4) ||
-        e->best_value.ensure(16) || e->population.ensure((size_t)c.pop * c.D * 4) || e->values.ensure((size_t)c.pop * 4))
+    const CemDev c = make_cem(p, n_env);
+    const size_t nd = (size_t)n_env * c.D, npop = (size_t)n_env * c.pop;
+    if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure((size_t)n_env * 4 + 16) ||
+        e->population.ensure(npop * c.D * 4) || e->values.ensure(npop * 4))
         return 1;
-    hipLaunchKernelGGL(cem_init_kernel, dim3((c.D + 255) / 256), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
+    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
                        e->disp.as<float>(), e->best_value.as<float>());
     HCHECK(hipGetLastError());
-    HCHECK(hipMemsetAsync(e->best_solution.p, 0, (size_t)c.D * 4, st));
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
     hipets_rollout_opts ro{};
     ro.mode = HIPETS_MODE_FAST;
     ro.seed = seed;
+    ro.n_env = n_env;
+    int n2 = 1;
+    while (n2 < c.pop) n2 <<= 1;
     for (int i = 0; i < p->num_iterations; ++i) {
         const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
-        if (hipets_cem_sample(e, p, e->mu.as<float>(), e->disp.as<float>(), lower, upper, nullptr, seed, sid,
-                              e->population.as<float>(), stream))
-            return 1;
+        const long long n = (long long)npop * c.D;
+        hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
+                           lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
+                           e->population.as<float>());
+        HCHECK(hipGetLastError());
         ro.stream_id = sid;
-        if (hipets_rollout(e, e->population.as<float>(), s0, c.pop, c.H, P, &ro, e->values.as<float>(), stream)) return 1;
-        if (hipets_cem_refit(e, p, e->values.as<float>(), e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(),
-                             e->best_value.as<float>(), e->best_solution.as<float>(), nullptr, stream))
-            return 1;
+        if (hipets_rollout(e, e->population.as<float>(), s0, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream)) return 1;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8, st, c, e->values.as<float>(),
+                           e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                           e->best_solution.as<float>(), (int*)nullptr);
+        HCHECK(hipGetLastError());
     }
-    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, (size_t)c.D * 4, hipMemcpyDeviceToDevice, st));
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

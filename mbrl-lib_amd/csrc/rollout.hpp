@@ -78,6 +78,7 @@ struct RolloutArgs {
     float* trace_next_obs;
     float* trace_rewards;
     long long* phase_cycles;  // optional [kWaves][16 phases] cycle counters of workgroup 0 (profiling aid)
+    int pop_env;               // FAST batched planning: candidates per environment (candidate c starts from s0[c / pop_env]); 0 = one env
     const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
     int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
 };
@@ -558,7 +559,11 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         const int s = i / md.obs_dim, d = i % md.obs_dim;
         const int rid = sm.rowid[s];
         float v = 0.f;
-        if (fast) v = ra.init_states ? (rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f) : ra.s0[d];
+        if (fast) {
+            if (ra.init_states) v = rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f;
+            else if (ra.pop_env > 0) v = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
+            else v = ra.s0[d];
+        }
         else if (rid >= 0) v = ra.state[(size_t)rid * md.obs_dim + d];
         sm.state[i] = v;
     }

@@ -9,6 +9,7 @@ from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_ch
 from .engine import Engine  # noqa: F401
 from .planning import (  # noqa: F401
     Agent,
+    BatchedCEMAgent,
     CEMOptimizer,
     HipTrajectoryEvalFn,
     ICEMOptimizer,

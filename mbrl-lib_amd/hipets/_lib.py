@@ -45,6 +45,7 @@ class RolloutOpts(C.Structure):
         ("rows_per_group", C.c_int32),
         ("phase_cycles", C.c_void_p),
         ("no_sample", C.c_int32),
+        ("n_env", C.c_int32),
     ]
 
 
@@ -77,6 +78,7 @@ SYMBOLS = {
     "hipets_icem_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_icem_shift": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_plan_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_plan_cem_batched": (C.c_int, [_P, C.POINTER(CemParams), C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
     "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }

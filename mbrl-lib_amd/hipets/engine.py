@@ -112,7 +112,7 @@ class Engine:
                 stream_id: int = 0, member_schedule: Optional[torch.Tensor] = None,
                 trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
                 rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
-                phase_cycles: Optional[torch.Tensor] = None) -> torch.Tensor:
+                phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1) -> torch.Tensor:
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -123,10 +123,13 @@ class Engine:
         if A != self.spec.act_dim:
             raise ValueError(f"action dim {A} != model act_dim {self.spec.act_dim}")
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
-        if s0.shape[0] != self.spec.obs_dim:
-            raise ValueError(f"initial_state has {s0.shape[0]} dims, model obs_dim is {self.spec.obs_dim}")
+        if s0.shape[0] != self.spec.obs_dim * max(1, n_env):
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected n_env x obs_dim = {max(1, n_env)} x {self.spec.obs_dim}")
+        if n_env > 1 and (mode != "fast" or pop % n_env):
+            raise ValueError("batched rollouts (n_env > 1) need mode='fast' and a population divisible by n_env")
         B = pop * num_particles
         o = RolloutOpts()
+        o.n_env = int(n_env)
         o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
@@ -328,22 +331,26 @@ class Engine:
         return out
 
     def plan_cem(self, p: CemParams, x0, lower, upper, s0: np.ndarray, num_particles: int, seed: int = 0,
-                 plan_id: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 plan_id: int = 0, out: Optional[torch.Tensor] = None, n_env: int = 1) -> torch.Tensor:
+        """Whole CEM plan on the device.  n_env > 1: x0 / out are [n_env, H, A], s0 is [n_env, obs_dim]; p.population_size is
+        per environment (hipets_plan_cem_batched)."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
         shp = (p.horizon, p.act_dim)
-        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+        _check_dev(x0, torch.float32, dev, "x0", numel=n_env * p.horizon * p.act_dim)
+        xshp = tuple(x0.shape)  # [H, A] or [n_env, H, A]
+        for n_, t in (("lower", lower), ("upper", upper)):
             _check_dev(t, torch.float32, dev, n_, shp)
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
-        if s0.shape[0] != self.spec.obs_dim:
-            raise ValueError(f"initial_state has {s0.shape[0]} dims, model obs_dim is {self.spec.obs_dim}")
+        if s0.shape[0] != self.spec.obs_dim * n_env:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {n_env} x {self.spec.obs_dim}")
         if out is None:
-            out = torch.empty(shp, dtype=torch.float32, device=dev)
+            out = torch.empty(xshp, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(self._lib.hipets_plan_cem(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper),
-                                                 s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
-                                                 int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+            _lib.check(self._lib.hipets_plan_cem_batched(self._h, C.byref(p), int(n_env), _ptr(x0), _ptr(lower), _ptr(upper),
+                                                         s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                         int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------------

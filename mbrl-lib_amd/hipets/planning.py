@@ -592,6 +592,54 @@ class TrajectoryOptimizerAgent(Agent):
         return self.optimizer.optimize(_BoundObjective(self.trajectory_eval_fn, obs))
 
 
+class BatchedCEMAgent(Agent):
+    """Batched planning: one CEM plan per environment for ``n_env`` environments (vectorised envs,
+    MPC for many agents) in ONE set of launches.  Same algorithm per environment as ``TrajectoryOptimizerAgent`` +
+    ``CEMOptimizer`` (warm start shifted by ``replan_freq`` per environment, trajectory_opt.py:563-567); a single cfg2
+    plan leaves 36 of 256 CUs idle, a batch fills the chip."""
+
+    def __init__(self, eval_fn: HipTrajectoryEvalFn, n_env: int, action_lb: Sequence[float], action_ub: Sequence[float],
+                 planning_horizon: int, num_iterations: int, elite_ratio: float, population_size: int, alpha: float,
+                 return_mean_elites: bool = True, clipped_normal: bool = False, replan_freq: int = 1, seed: int = 0):
+        if eval_fn.mode != "fast":
+            raise ValueError("batched planning runs the FAST rollout path")
+        self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
+        self.n_env, self.horizon, self.replan_freq = int(n_env), int(planning_horizon), int(replan_freq)
+        lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)
+        A = lb.shape[0]
+        self.lower = torch.tensor(np.tile(lb, (planning_horizon, 1)), device=self.device).contiguous()
+        self.upper = torch.tensor(np.tile(ub, (planning_horizon, 1)), device=self.device).contiguous()
+        self.initial_solution = torch.tensor((lb + ub) / 2, device=self.device).repeat(self.n_env, planning_horizon, 1).contiguous()
+        self.previous_solution = self.initial_solution.clone()
+        self.elite_num = int(np.ceil(population_size * elite_ratio))
+        self._params = Engine.cem_params(population_size, planning_horizon, A, num_iterations, self.elite_num, alpha,
+                                         return_mean_elites, clipped_normal, unbiased_var=True)
+        self.seed, self.calls = int(seed), 0
+
+    def reset(self):
+        self.previous_solution = self.initial_solution.clone()
+
+    def plan(self, obs_batch: np.ndarray, **_kwargs) -> np.ndarray:
+        obs_batch = np.asarray(obs_batch, dtype=np.float32)
+        assert obs_batch.shape[0] == self.n_env
+        self.eval_fn.refresh()
+        if self.engine.spec is not self.eval_fn.spec:
+            self.engine.set_model(self.eval_fn.spec)
+        self.eval_fn.check_batch(self._params.population_size)
+        self.calls += 1
+        best = self.engine.plan_cem(self._params, self.previous_solution, self.lower, self.upper, obs_batch,
+                                    self.eval_fn.num_particles, seed=self.seed ^ self.eval_fn.seed, plan_id=self.calls,
+                                    n_env=self.n_env)
+        self.previous_solution = best.roll(-self.replan_freq, dims=1)
+        self.previous_solution[:, -self.replan_freq:] = self.initial_solution[:, :1]
+        self.previous_solution = self.previous_solution.contiguous()
+        return best.cpu().numpy()
+
+    def act(self, obs_batch: np.ndarray, **_kwargs) -> np.ndarray:
+        """One action per environment, [n_env, A]."""
+        return self.plan(obs_batch)[:, 0]
+
+
 def complete_agent_cfg(env, agent_cfg):
     """The subset of mbrl/planning/core.py:71-123 a trajectory-optimizer agent config needs: fill
     ``action_lb`` / ``action_ub`` placeholders ("???" or missing) from the action space."""

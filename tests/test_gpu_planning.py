@@ -332,3 +332,59 @@ def test_icem_and_mppi_with_engine_objective(engine):
     eps = torch.randn(H, B, obs, generator=g)
     r = po.rollout(om, cands, s0, 50, perms=perms, eps=eps)
     assert (r[:3] > r[3:].max() + 0.5).all(), r
+
+
+def test_batched_rollout_replayed_through_oracle_per_environment(engine):
+    """n_env environments in one FAST launch: candidates of environment g start from s0[g]; replayed per environment."""
+    obs, act, H, P, pop_env, n_env = 17, 6, 5, 5, 30, 4
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=8)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(2)
+    actions = torch.rand(n_env * pop_env, H, act, generator=g) * 2 - 1
+    s0 = (torch.randn(n_env, obs, generator=g) * 0.3).numpy().astype(np.float32)
+    seed, sid = 5, 9
+    out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid, n_env=n_env).cpu()
+    pop = n_env * pop_env
+    nwg, r = engine.fast_geometry(pop, P, H)
+    sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
+    eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
+    rows = torch.arange(pop * P)
+    wg = ((rows // P) // (16 * r)) * P + rows % P
+    members = torch.stack([sched[t][wg].long() for t in range(H)])
+    for e_ in range(n_env):
+        sl = slice(e_ * pop_env * P, (e_ + 1) * pop_env * P)
+        ref = po.rollout(om, actions[e_ * pop_env:(e_ + 1) * pop_env], s0[e_], P, members=members[:, sl], eps=eps[:, sl])
+        assert torch.allclose(out[e_ * pop_env:(e_ + 1) * pop_env], ref, rtol=0, atol=1e-4)
+
+
+def test_batched_cem_planning(engine):
+    """hipets_plan_cem_batched: n_env = 1 is bit-identical to the single-environment plan; a batch gives every environment
+    a good plan for ITS observation (scored by the oracle), and the warm start shifts per environment."""
+    from hipets.planning import _BoundObjective
+
+    obs, act, H, P, pop, n_env = 17, 6, 8, 10, 200, 3
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=6)
+    om.max_logvar = torch.full_like(om.max_logvar, -8.0)
+    spec = to_spec(om, obs, act)
+    fn = hipets.make_eval_fn(spec, P, engine=engine, seed=3)
+    lb, ub = [-1.0] * act, [1.0] * act
+    single = hipets.CEMOptimizer(4, 0.1, pop, [lb] * H, [ub] * H, 0.1, DEV, return_mean_elites=True, seed=7)
+    s0 = (np.random.default_rng(1).standard_normal((n_env, obs)) * 0.3).astype(np.float32)
+    one = single.optimize(_BoundObjective(fn, s0[0]), x0=torch.zeros(H, act))
+    agent1 = hipets.BatchedCEMAgent(fn, 1, lb, ub, H, 4, 0.1, pop, 0.1, seed=7)
+    assert torch.equal(torch.from_numpy(agent1.plan(s0[:1]))[0], one.cpu())
+    agent = hipets.BatchedCEMAgent(fn, n_env, lb, ub, H, 4, 0.1, pop, 0.1, seed=7)
+    plans = agent.plan(s0)
+    assert plans.shape == (n_env, H, act) and np.isfinite(plans).all()
+    prev = agent.previous_solution.cpu().numpy()
+    assert np.allclose(prev[:, :-1], plans[:, 1:]) and np.allclose(prev[:, -1], 0.0)
+    acts = agent.act(s0)
+    assert acts.shape == (n_env, act)
+    g = torch.Generator().manual_seed(0)
+    for e_ in range(n_env):
+        cands = torch.cat([torch.from_numpy(plans[e_])[None], torch.rand(7, H, act, generator=g) * 2 - 1])
+        B = 8 * 50
+        perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
+        eps = torch.randn(H, B, obs, generator=g)
+        r = po.rollout(om, cands, s0[e_], 50, perms=perms, eps=eps)
+        assert r[0] > r[1:].max() + 0.5, (e_, r)
