@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra batched-planning measurement")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -198,6 +199,31 @@ def main():
         extra = {"workload": f"configs[2]: the pop={POP} plan sharded over {world} ranks (strong scaling)", "value": args.steps * ITERS * POP *
                  PARTICLES * HORIZON / e2, "unit": "candidate-steps/s", "ms_per_step": 1e3 * e2 / args.steps, "plans_per_s": args.steps / e2}
 
+    # extra (N = 1 only, outside the timed region above): batched planning, 8 cfg2 environments per launch -- the same
+    # kernels with all 256 CUs busy (a single cfg2 plan has 2.4 row tiles per CU).  Reported, never the headline value.
+    batched = None
+    if world == 1 and not args.no_batched:
+        n_env = 8
+        agent = hipets.BatchedCEMAgent(eval_fn, n_env, [-1.0] * ACT, [1.0] * ACT, HORIZON, ITERS, ELITE_RATIO, POP, ALPHA, seed=0)
+        s0b = (np.random.default_rng(0).standard_normal((n_env, OBS)) * 0.1).astype(np.float32)
+        for _ in range(2):
+            agent.plan(s0b)
+        engine.timing_enable(True)
+        engine.timing_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = max(2, args.steps // 8)
+        for _ in range(nb):
+            agent.plan(s0b)
+        torch.cuda.synchronize()
+        eb = time.perf_counter() - t0
+        lb_, kms_ = engine.timing_read(reset=True)
+        engine.timing_enable(False)
+        tf = spec.flops_per_candidate_step() * n_env * POP * PARTICLES * HORIZON / (kms_ / max(lb_, 1) * 1e-3) / 1e12
+        batched = {"workload": f"{n_env} x configs[1] environments planned in one set of launches (hipets_plan_cem_batched)",
+                   "value": nb * n_env * ITERS * POP * PARTICLES * HORIZON / eb, "unit": "candidate-steps/s",
+                   "ms_per_env_plan": 1e3 * eb / nb / n_env, "rollout_kernel_tflops": tf, "rollout_kernel_frac_of_fp32_peak": tf / PEAK_FP32_TFLOPS}
+
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     value = args.steps * cand_steps_per_plan / elapsed
     flops_cs = spec.flops_per_candidate_step()
@@ -232,6 +258,8 @@ def main():
     }
     if extra is not None:
         out["cfg3_strong"] = extra
+    if batched is not None:
+        out["batched_planning"] = batched
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)

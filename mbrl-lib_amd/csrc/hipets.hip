@@ -146,7 +146,9 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         const long long groups = (tiles_total_per_slice + R - 1) / R;
         const long long nwg = groups * slices;
         const long long rounds = (nwg + e->num_cu - 1) / e->num_cu;
-        const double cost = (double)rounds * wave_units(C, R);
+        // measured on cfg2: a (round x unit) costs ~10 % more at R = 1, 2 (each B fragment feeds fewer MFMAs)
+        const double reuse_penalty = R == 1 ? 1.10 : (R == 2 ? 1.08 : 1.0);
+        const double cost = (double)rounds * wave_units(C, R) * reuse_penalty;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = R;

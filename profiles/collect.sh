@@ -10,8 +10,8 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-SHORT="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-batched"
+SHORT="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batched"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq -o pmc -- $SHORT > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -o pmc -- $SHORT > $OUT/pmc_lds.log 2>&1
