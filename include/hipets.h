@@ -42,7 +42,8 @@ enum { HIPETS_PROP_RANDOM_MODEL = 0, HIPETS_PROP_FIXED_MODEL = 1, HIPETS_PROP_EX
 enum { HIPETS_OBS_NONE = 0, HIPETS_OBS_HALFCHEETAH = 1, HIPETS_OBS_CARTPOLE_PETS = 2 };
 /* reward_fn (mbrl/env/reward_fns.py:10-53); LEARNED = last model output (model_env.py:124-128) */
 enum { HIPETS_REW_LEARNED = 0, HIPETS_REW_CARTPOLE = 1, HIPETS_REW_CARTPOLE_PETS = 2, HIPETS_REW_INVERTED_PENDULUM = 3,
-       HIPETS_REW_HALFCHEETAH = 4, HIPETS_REW_PUSHER = 5 };
+       HIPETS_REW_HALFCHEETAH = 4, HIPETS_REW_PUSHER = 5,
+       HIPETS_REW_NONE = 6 /* rewards are computed by the caller (arbitrary Python reward_fn on hipets_step's next_obs) */ };
 /* termination_fn (mbrl/env/termination_fns.py:12-95) */
 enum { HIPETS_TERM_NONE = 0, HIPETS_TERM_CARTPOLE = 1, HIPETS_TERM_INVERTED_PENDULUM = 2, HIPETS_TERM_HOPPER = 3,
        HIPETS_TERM_WALKER2D = 4, HIPETS_TERM_ANT = 5, HIPETS_TERM_HUMANOID = 6 };

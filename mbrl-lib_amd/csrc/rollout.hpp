@@ -432,6 +432,7 @@ __device__ __forceinline__ float reward_eval(const float* s, const float* a, int
             for (int i = 0; i < act_dim; ++i) sq += a[i] * a[i];
             return -(obs_cost + 0.1f * sq);
         }
+        case HIPETS_REW_NONE: return 0.0f;  // the caller evaluates its own reward_fn on the returned next_obs
         default: return learned;  // model_env.py:124-128 with reward_fn None
     }
 }

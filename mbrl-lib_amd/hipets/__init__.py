@@ -18,6 +18,7 @@ from .planning import (  # noqa: F401
     Optimizer,
     TrajectoryOptimizer,
     TrajectoryOptimizerAgent,
+    UnfusedTrajectoryEvalFn,
     complete_agent_cfg,
     create_trajectory_optim_agent_for_model,
     get_engine,

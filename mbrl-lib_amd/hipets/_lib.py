@@ -14,7 +14,7 @@ MAX_LAYERS = 8
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
 PROP = {"random_model": 0, "fixed_model": 1, "expectation": 2}
 OBS = {"none": 0, "halfcheetah": 1, "cartpole_pets": 2}
-REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendulum": 3, "halfcheetah": 4, "pusher": 5}
+REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendulum": 3, "halfcheetah": 4, "pusher": 5, "none": 6}
 TERM = {"no_termination": 0, "cartpole": 1, "inverted_pendulum": 2, "hopper": 3, "walker2d": 4, "ant": 5, "humanoid": 6}
 NORM = {"none": 0, "f32": 1, "f64": 2}
 MODE_EXACT, MODE_FAST = 0, 1

@@ -22,7 +22,7 @@ class UnsupportedModelError(ValueError):
 
 
 _ACT_BY_CLASS = {"SiLU": "silu", "ReLU": "relu", "LeakyReLU": "leaky_relu", "Tanh": "tanh", "Sigmoid": "sigmoid"}
-_KNOWN_REWARDS = ("cartpole", "cartpole_pets", "inverted_pendulum", "halfcheetah", "pusher")
+_KNOWN_REWARDS = ("cartpole", "cartpole_pets", "inverted_pendulum", "halfcheetah", "pusher", "none")
 _KNOWN_TERMS = ("no_termination", "cartpole", "inverted_pendulum", "hopper", "walker2d", "ant", "humanoid")
 
 
@@ -45,8 +45,10 @@ class ModelSpec:
     no_delta_list: Sequence[int] = field(default_factory=list)
     learned_rewards: bool = False
     obs_process: str = "none"
-    reward: Optional[str] = "halfcheetah"  # None => learned reward (last model output)
+    reward: Optional[str] = "halfcheetah"  # None => learned reward (last model output); "none" => caller's callable
     termination: str = "no_termination"
+    custom_reward_fn: Optional[object] = None  # arbitrary torch callables (act, next_obs) -> [B,1]; UNFUSED path only
+    custom_termination_fn: Optional[object] = None
 
     # ---- derived ---------------------------------------------------------------------------
     @property
@@ -107,9 +109,14 @@ def _fn_name(fn) -> Optional[str]:
     return getattr(fn, "__name__", None)
 
 
-def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optional[int] = None) -> ModelSpec:
+def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optional[int] = None,
+                        allow_custom_fns: bool = False) -> ModelSpec:
     """Read a live ``mbrl.models.ModelEnv`` (or anything shaped like it).  No copy of the big tensors:
-    the spec holds references to the live parameters; ``Engine.set_model`` packs them on device."""
+    the spec holds references to the live parameters; ``Engine.set_model`` packs them on device.
+
+    ``allow_custom_fns``: a ``reward_fn`` / ``termination_fn`` that is not one of mbrl.env's closed forms is kept as a
+    Python callable (``spec.custom_reward_fn`` / ``spec.custom_termination_fn``) for the UNFUSED path (the model
+    transition stays fused, the callables run as torch ops between steps) instead of raising."""
     dm = model_env.dynamics_model
     mlp = getattr(dm, "model", None)
     if mlp is None or not hasattr(mlp, "hidden_layers") or not hasattr(mlp, "mean_and_logvar"):
@@ -148,6 +155,13 @@ def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optio
     od = obs_dim if obs_dim is not None else int(model_env.observation_space.shape[0])
     ad = act_dim if act_dim is not None else int(model_env.action_space.shape[0])
     rew = model_env.reward_fn
+    rew_name, term_name = _fn_name(rew), _fn_name(model_env.termination_fn)
+    custom_rew = custom_term = None
+    if allow_custom_fns:
+        if rew is not None and rew_name not in _KNOWN_REWARDS:
+            custom_rew, rew_name = rew, "none"
+        if term_name not in _KNOWN_TERMS:
+            custom_term, term_name = model_env.termination_fn, "no_termination"
     spec = ModelSpec(
         weights=ws, biases=bs, obs_dim=od, act_dim=ad,
         min_logvar=None if deterministic else mlp.min_logvar.detach(),
@@ -159,8 +173,9 @@ def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optio
         norm_std=norm.std.detach() if norm is not None else None,
         target_is_delta=bool(dm.target_is_delta), no_delta_list=list(dm.no_delta_list or []),
         learned_rewards=bool(dm.learned_rewards), obs_process=obs_process,
-        reward=_fn_name(rew), termination=_fn_name(model_env.termination_fn),
+        reward=rew_name, termination=term_name,
     )
+    spec.custom_reward_fn, spec.custom_termination_fn = custom_rew, custom_term
     spec.validate()
     return spec
 

@@ -210,10 +210,90 @@ class ModelEnv:
         return self._eval(initial_state, action_sequences)
 
 
-def make_eval_fn(model, num_particles: int, **kw) -> HipTrajectoryEvalFn:
+class UnfusedTrajectoryEvalFn:
+    """``trajectory_eval_fn`` for models whose ``reward_fn`` / ``termination_fn`` are arbitrary Python callables
+    (SURVEY.md section 2.1 row 6 "documented unfused fallback"): the horizon loop of
+    ``ModelEnv.evaluate_action_sequences`` (model_env.py:178-191) runs on the host, every model transition is ONE fused
+    ``hipets_step`` launch (input build, ensemble MLP, sampling, delta), and the user's callables run as torch ops on
+    the returned device tensors.  Same block-balanced TS1 / Philox randomness as the fused FAST path."""
+
+    mode = "unfused"
+
+    def __init__(self, model, num_particles: int, reward_fn=None, termination_fn=None, engine: Optional[Engine] = None,
+                 seed: int = 0, device=None):
+        self.num_particles, self.seed, self.calls = int(num_particles), int(seed), 0
+        self._model_env, self._version = None, None
+        if isinstance(model, ModelSpec):
+            spec = model
+            dev = device if device is not None else "cuda:0"
+        else:
+            self._model_env = model
+            spec = spec_from_model_env(model, allow_custom_fns=True)
+            dev = device if device is not None else getattr(model, "device", "cuda:0")
+            self._version = model_version(model)
+        self.reward_fn = reward_fn if reward_fn is not None else spec.custom_reward_fn
+        self.termination_fn = termination_fn if termination_fn is not None else spec.custom_termination_fn
+        self.engine = engine if engine is not None else get_engine(dev)
+        self.device = self.engine.device
+        self.spec = spec
+        self.engine.set_model(spec)
+
+    def refresh(self):
+        if self._model_env is not None and model_version(self._model_env) != self._version:
+            self.spec = spec_from_model_env(self._model_env, allow_custom_fns=True)
+            self.engine.set_model(self.spec)
+            self._version = model_version(self._model_env)
+
+    def check_batch(self, pop: int):
+        B, M = pop * self.num_particles, len(self.spec.members)
+        if B % M != 0:
+            raise ValueError(
+                f"GaussianMLP ensemble requires batch size to be a multiple of the "
+                f"number of models. Current batch size is {B} for "
+                f"{M} models."
+            )
+
+    def __call__(self, initial_state: np.ndarray, action_sequences: torch.Tensor) -> torch.Tensor:
+        self.refresh()
+        if self.engine.spec is not self.spec:
+            self.engine.set_model(self.spec)
+        a_seq = action_sequences.to(device=self.device, dtype=torch.float32)
+        pop, H, _ = a_seq.shape
+        P = self.num_particles
+        self.check_batch(pop)
+        self.calls += 1
+        obs = torch.as_tensor(np.asarray(initial_state, np.float32), device=self.device).repeat(pop * P, 1).contiguous()
+        total = torch.zeros(pop * P, 1, device=self.device)
+        terminated = torch.zeros(pop * P, 1, dtype=torch.bool, device=self.device)
+        for t in range(H):
+            act = torch.repeat_interleave(a_seq[:, t, :], P, dim=0).contiguous()  # model_env.py:179-182
+            nobs, rew, done = self.engine.step(obs, act, mode="fast", sample=True, seed=self.seed, stream_id=self.calls * 4096 + t)
+            if self.reward_fn is not None:
+                rew = self.reward_fn(act, nobs)
+            if self.termination_fn is not None:
+                done = self.termination_fn(act, nobs)
+            rew = rew.clone()
+            rew[terminated] = 0  # :186
+            terminated |= done  # :187
+            total += rew  # :188
+            obs = nobs
+        return total.reshape(-1, P).mean(dim=1)
+
+
+def make_eval_fn(model, num_particles: int, **kw):
     """``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))`` on a stock or a
-    hipets agent (seam 3 of SURVEY.md section 8b)."""
-    return HipTrajectoryEvalFn(model, num_particles, **kw)
+    hipets agent (seam 3 of SURVEY.md section 8b).  Returns the fully fused objective when reward / termination are
+    mbrl.env closed forms, the unfused one (fused model step + Python callables) when they are arbitrary callables."""
+    try:
+        return HipTrajectoryEvalFn(model, num_particles, **kw)
+    except UnsupportedModelError:
+        if isinstance(model, ModelSpec):
+            raise
+        spec = spec_from_model_env(model, allow_custom_fns=True)  # raises again if something else is unsupported
+        if spec.custom_reward_fn is None and spec.custom_termination_fn is None:
+            raise
+        kw2 = {k: v for k, v in kw.items() if k in ("engine", "seed", "device")}
+        return UnfusedTrajectoryEvalFn(model, num_particles, **kw2)
 
 
 class _BoundObjective:
