@@ -112,6 +112,36 @@ def cpu_baseline(budget_s=20.0):
             "plans_per_s_extrapolated": v / (ITERS * POP * PARTICLES * HORIZON)}
 
 
+def torch_rocm_port(device, plans=2):
+    """Informational second comparator: the SAME ATen op sequence as the reference
+    (the oracle is bitwise equal to it on CPU) executed on this MI355X through PyTorch-ROCm, i.e. what
+    `device="cuda:0"` buys the unmodified reference: ~55 launches per rollout step, launch-bound."""
+    from oracle import pets_oracle as po
+
+    om = po.make_synthetic_model(OBS, ACT, ensemble_size=ENSEMBLE, hid=HID, num_layers=LAYERS, seed=0, nontrivial_stats=False)
+    for k in ("weights", "biases"):
+        setattr(om, k, [t.to(device) for t in getattr(om, k)])
+    for k in ("min_logvar", "max_logvar", "norm_mean", "norm_std"):
+        setattr(om, k, getattr(om, k).to(device))
+    s0 = (np.random.default_rng(0).standard_normal(OBS) * 0.1).astype(np.float32)
+    lb, ub = -torch.ones(HORIZON, ACT, device=device), torch.ones(HORIZON, ACT, device=device)
+    gen = torch.Generator(device=device).manual_seed(0)
+    obj = lambda pop_: po.rollout(om, pop_, s0, PARTICLES, global_rng=True, generator=gen)  # noqa: E731
+
+    def plan():
+        return po.cem_optimize(obj, torch.zeros(HORIZON, ACT, device=device), lb, ub, ITERS, ELITE_RATIO, POP, ALPHA, return_mean_elites=True)
+
+    plan()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(plans):
+        plan()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / plans
+    return {"value": ITERS * POP * PARTICLES * HORIZON / dt, "unit": "candidate-steps/s", "ms_per_plan": 1e3 * dt,
+            "what": "reference op sequence (oracle port) on this GPU via PyTorch-ROCm eager ops, not the product path"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +294,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
             out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            try:
+                out["torch_rocm_port"] = torch_rocm_port(device)
+            except Exception as exc:  # informational leg only
+                out["torch_rocm_port"] = {"error": str(exc)[:200]}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

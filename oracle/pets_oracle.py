@@ -73,7 +73,7 @@ class OracleModel:
 
 
 def term_no_termination(act, nobs):  # env/termination_fns.py:58-63
-    return torch.zeros(len(nobs), 1, dtype=torch.bool)
+    return torch.zeros(len(nobs), 1, dtype=torch.bool, device=nobs.device)
 
 
 def term_cartpole(act, nobs):  # env/termination_fns.py:29-44
@@ -136,7 +136,7 @@ def rew_inverted_pendulum(act, nobs):  # env/reward_fns.py:27-30
 
 
 def rew_cartpole_pets(act, nobs):  # env/reward_fns.py:16-24
-    goal = torch.tensor([0.0, 0.6])
+    goal = torch.tensor([0.0, 0.6], device=nobs.device)
     x0 = nobs[:, :1]
     theta = nobs[:, 1:2]
     ee = torch.cat([x0 - 0.6 * theta.sin(), -0.6 * theta.cos()], dim=1)
@@ -152,7 +152,7 @@ def rew_halfcheetah(act, nobs):  # env/reward_fns.py:33-38
 
 
 def rew_pusher(act, nobs):  # env/reward_fns.py:41-53
-    goal = torch.tensor([0.45, -0.05, -0.323])
+    goal = torch.tensor([0.45, -0.05, -0.323], device=nobs.device)
     tip, obj = nobs[:, 14:17], nobs[:, 17:20]
     tip_obj = (tip - obj).abs().sum(axis=1)
     obj_goal = (goal - obj).abs().sum(axis=1)
@@ -321,9 +321,10 @@ def rollout(
     pop, H, A = actions.shape
     P = num_particles
     B = pop * P
-    x = torch.from_numpy(np.tile(np.asarray(s0), (B, 1)).astype(np.float32))  # model_env.py:170-174
-    tot = torch.zeros(B, 1)
-    term = torch.zeros(B, 1, dtype=torch.bool)
+    dev = actions.device  # CPU for every parity use; a GPU only in bench.py's informational PyTorch-ROCm leg
+    x = torch.from_numpy(np.tile(np.asarray(s0), (B, 1)).astype(np.float32)).to(dev)  # model_env.py:170-174
+    tot = torch.zeros(B, 1, device=dev)
+    term = torch.zeros(B, 1, dtype=torch.bool, device=dev)
     out = m.weights[-1].shape[-1] // (1 if m.deterministic else 2)
     fixed_perm = None
     if m.propagation == "fixed_model" and members is None:
@@ -333,7 +334,7 @@ def rollout(
             fixed_perm = perms if perms.ndim == 1 else perms[0]
         else:
             assert global_rng
-            fixed_perm = torch.randperm(B)
+            fixed_perm = torch.randperm(B, device=dev)
     rew_fn = REWARD_FNS[m.reward] if m.reward is not None else None
     term_fn = TERMINATION_FNS[m.termination]
     for t in range(H):
@@ -348,7 +349,7 @@ def rollout(
                 perm = perms[t]
             else:
                 assert global_rng
-                perm = torch.randperm(B)  # gaussian_mlp.py:203-205 (GLOBAL rng)
+                perm = torch.randperm(B, device=dev)  # gaussian_mlp.py:203-205 (GLOBAL rng)
         elif m.propagation == "fixed_model":
             perm = fixed_perm
         mean, logvar = ensemble_forward(m, inp, perm, mem)
@@ -359,7 +360,7 @@ def rollout(
             if eps is not None:
                 e = eps[t]
             else:
-                e = torch.empty(B, out).normal_(0.0, 1.0, generator=generator)
+                e = torch.empty(B, out, device=dev).normal_(0.0, 1.0, generator=generator)
             pred = mean + std * e  # == torch.normal(mean, std, generator) on CPU
         nobs = pred[:, :-1] if m.learned_rewards else pred  # one_dim_tr_model.py:280
         if m.target_is_delta:  # :281-286
@@ -394,7 +395,7 @@ def truncated_normal_(t: torch.Tensor, mean: float = 0.0, std: float = 1.0,
         n = int(torch.sum(cond).item())
         if n == 0:
             break
-        t[cond] = torch.normal(mean, std, size=(n,), generator=generator)
+        t[cond] = torch.normal(mean, std, size=(n,), generator=generator, device=t.device)
     return t
 
 
@@ -471,9 +472,9 @@ def cem_optimize(
         if noise is not None:
             z = noise[i]
         elif clipped_normal:
-            z = torch.randn((population_size,) + tuple(x0.shape))
+            z = torch.randn((population_size,) + tuple(x0.shape), device=x0.device)
         else:
-            z = truncated_normal_(torch.zeros((population_size,) + tuple(x0.shape)))
+            z = truncated_normal_(torch.zeros((population_size,) + tuple(x0.shape), device=x0.device))
         if clipped_normal:  # :116-120
             p = mu + disp * z
             p = torch.where(p > lower, p, lower)
