@@ -254,6 +254,26 @@ def main():
                    "value": nb * n_env * ITERS * POP * PARTICLES * HORIZON / eb, "unit": "candidate-steps/s",
                    "ms_per_env_plan": 1e3 * eb / nb / n_env, "rollout_kernel_tflops": tf, "rollout_kernel_frac_of_fp32_peak": tf / PEAK_FP32_TFLOPS}
 
+    # extra (N = 1): the same plan with the reference's EXACT propagation semantics (one global balanced random
+    # permutation of all 10 000 rows per step, per-step launches, state through HBM) instead of FAST mode's
+    # block-balanced schedule -- shows what the fast mode's restructuring is worth and that it is not needed for speed-up.
+    exact_sem = None
+    if world == 1 and not args.no_batched:
+        fn_x = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode="exact_device")
+        opt_x = hipets.CEMOptimizer(ITERS, ELITE_RATIO, POP, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
+        obj_x = _BoundObjective(fn_x, s0)
+        for _ in range(2):
+            opt_x.optimize(obj_x, x0=x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nx = max(2, args.steps // 5)
+        for _ in range(nx):
+            opt_x.optimize(obj_x, x0=x0)
+        torch.cuda.synchronize()
+        ex = time.perf_counter() - t0
+        exact_sem = {"workload": "configs[1] with mode='exact_device': reference TS1 semantics (global randperm per step), device RNG",
+                     "value": nx * ITERS * POP * PARTICLES * HORIZON / ex, "unit": "candidate-steps/s", "ms_per_plan": 1e3 * ex / nx}
+
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     value = args.steps * cand_steps_per_plan / elapsed
     flops_cs = spec.flops_per_candidate_step()
@@ -290,6 +310,8 @@ def main():
         out["cfg3_strong"] = extra
     if batched is not None:
         out["batched_planning"] = batched
+    if exact_sem is not None:
+        out["exact_semantics"] = exact_sem
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)

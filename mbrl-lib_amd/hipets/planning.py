@@ -49,7 +49,9 @@ class HipTrajectoryEvalFn:
     ``ModelTrainer.train`` changed them) or from a ``ModelSpec``.  ``mode='fast'`` draws randomness
     in-kernel (Philox keyed by ``seed`` and a per-call counter); ``mode='exact'`` reproduces the
     reference's row->member maps from torch's RNGs, consumed in the reference's order
-    (one ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``).
+    (one ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``);
+    ``mode='exact_device'`` keeps the reference's exact semantics (global balanced permutation per step) but draws
+    on the device, for users who want reference-identical propagation statistics at GPU speed.
     """
 
     def __init__(self, model, num_particles: int, engine: Optional[Engine] = None, mode: str = "fast",
@@ -96,6 +98,21 @@ class HipTrajectoryEvalFn:
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
         self.calls += 1
         self.check_batch(a.shape[0])
+        if self.mode == "exact_device":
+            # the reference's exact propagation semantics (one GLOBAL balanced random permutation of all rows per step,
+            # gaussian_mlp.py:203-205; i.i.d. eps per row and dim) with the draws made by torch's device generator:
+            # argsort of uniforms = a uniform random permutation.  Pure index / noise plumbing, no host round trip.
+            pop, H, _ = a.shape
+            B = pop * self.num_particles
+            g = self._device_rng()
+            perms = eps = None
+            if self.spec.propagation == "random_model":
+                perms = torch.rand(H, B, device=self.device, generator=g).argsort(dim=1)
+            elif self.spec.propagation == "fixed_model":
+                perms = torch.rand(B, device=self.device, generator=g).argsort()
+            if not self.spec.deterministic:
+                eps = torch.randn(H, B, self.spec.out_dim, device=self.device, generator=g)
+            return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", perms=perms, eps=eps)
         if self.mode == "fast":
             return self.engine.rollout(a, initial_state, self.num_particles, mode="fast", seed=self.seed,
                                        stream_id=self.calls)
@@ -127,6 +144,11 @@ class HipTrajectoryEvalFn:
                 f"number of models. Current batch size is {B} for "
                 f"{M} models."
             )
+
+    def _device_rng(self):
+        if not hasattr(self, "_dev_rng"):
+            self._dev_rng = torch.Generator(device=self.device).manual_seed(self.seed)
+        return self._dev_rng
 
     def _cpu_rng(self):
         if self._rng is not None and self._rng.device.type == "cpu":
