@@ -138,12 +138,6 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     constexpr int EXn = EX > 0 ? EX : 1;
     f32x4 acc[CTn][R];
     f32x4 accx[EXn];
-#pragma unroll
-    for (int ct = 0; ct < CTn; ++ct)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[ct][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < EXn; ++e) accx[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
     const int exr[kMaxExtras] = {ex.r0, ex.r1, ex.r2, ex.r3};
@@ -163,6 +157,13 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + (c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
 #pragma unroll
     for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
+    // accumulators start at the bias (C input of the first MFMA) instead of zero: no add in the epilogue
+#pragma unroll
+    for (int ct = 0; ct < CTn; ++ct)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[ct][r] = CT > 0 ? bv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
 #pragma unroll
@@ -278,7 +279,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
             for (int r = 0; r < R; ++r) {
                 f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = actfn(acc[ct][r][i] + bv[ct][i]);
+                for (int i = 0; i < 4; ++i) v[i] = actfn(acc[ct][r][i]);
                 *reinterpret_cast<f32x4*>(out + (r * 16 + j) * ld + col) = v;
             }
         }
@@ -286,7 +287,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         for (int e = 0; e < EX; ++e) {
             f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = actfn(accx[e][i] + bvx[e][i]);
+            for (int i = 0; i < 4; ++i) v[i] = actfn(accx[e][i]);
             *reinterpret_cast<f32x4*>(out + (exr[e] * 16 + j) * ld + exc[e] * 16 + g4) = v;
         }
     };
