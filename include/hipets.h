@@ -203,8 +203,8 @@ int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t horizon, int32_t a
 
 /* Whole CEMOptimizer.optimize with the engine's rollout as objective, no host round trip
  * (replaces trajectory_opt.py:142-188 + the closure at :743-748).  x0/lower/upper DEVICE [H,A];
- * out DEVICE [H,A] = mu if return_mean_elites else best.  FAST mode rollouts. `scratch` may be
- * NULL (engine-owned workspace).                                                              */
+ * out DEVICE [H,A] = mu if return_mean_elites else best.  FAST mode rollouts; workspace is
+ * engine-owned.                                                                               */
 int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower,
                     const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
                     float* out, void* stream);
@@ -214,6 +214,36 @@ int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x
 int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_t n_env, const float* x0, const float* lower,
                             const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
                             float* out, void* stream);
+
+/* Whole MPPIOptimizer.optimize (trajectory_opt.py:238-311) with the engine's FAST rollout as objective.
+ * mean DEVICE [H,A] in-out = the optimizer's persistent self.mean: shifted one step in place (:257-258), then
+ * refined num_iterations times (:262-309); the refined mean is what optimize() returns (:311).              */
+int hipets_plan_mppi(hipets_engine* e, int32_t population_size, int32_t horizon, int32_t act_dim, int32_t num_iterations,
+                     double gamma, double beta, float* mean, const float* lower, const float* upper, const float* s0,
+                     int32_t num_particles, uint64_t seed, uint64_t plan_id, void* stream);
+
+typedef struct {
+    int32_t population_size;
+    int32_t horizon;
+    int32_t act_dim;
+    int32_t num_iterations;
+    int32_t elite_num;              /* ceil(pop * elite_ratio), trajectory_opt.py:368-370                      */
+    int32_t keep_elite_size;        /* ceil(keep_elite_frac * elite_num), rounded up to the module (:378-383)  */
+    int32_t population_size_module; /* 0 = none (:419-431)                                                     */
+    int32_t return_mean_elites;
+    double alpha;
+    double population_decay_factor;
+    double colored_noise_exponent;
+} hipets_icem_params;
+
+/* Whole ICEMOptimizer.optimize (trajectory_opt.py:391-487) with the engine's FAST rollout as objective.
+ * elite DEVICE [elite_num,H,A] in-out = the optimizer's persistent self.elite (read only when has_elite != 0,
+ * always written: it holds the last iteration's elites on return).  keep_idx DEVICE int32 [num_iterations,
+ * keep_elite_size] optional injected randperm(elite_num)[:keep] per iteration (:446-448); NULL => Philox.
+ * out DEVICE [H,A] = mu if return_mean_elites else best.                                                      */
+int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
+                     float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t num_particles,
+                     uint64_t seed, uint64_t plan_id, float* out, void* stream);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 /* When enabled, every rollout-kernel launch is bracketed by hipEvents on `stream`.              */

@@ -149,11 +149,6 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     if (improved && tid == 0) best_value[0] = top;
 }
 
-__global__ void fill_kernel(float* p, float v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // trajectory_opt.py:103-108: dispersion0 = ones (clipped) or ((ub - lb)^2) / 16; mu0 = x0
 __global__ void cem_init_kernel(const CemDev p, const float* x0, const float* lower, const float* upper, float* mu,
                                 float* disp, float* best_value) {

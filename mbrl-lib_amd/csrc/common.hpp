@@ -60,22 +60,4 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-// ---------------------------------------------------------------------------------------------
-// scalar math matching the ATen ops of the reference within f32 round-off
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float softplus_f(float x) {  // F.softplus, beta=1, threshold=20
-    return x > 20.0f ? x : log1pf(expf(x));
-}
-
-__device__ __forceinline__ float activate(float x, int act, float slope) {
-    switch (act) {
-        case HIPETS_ACT_SILU:  // x * sigmoid(x): v_exp_f32 + v_rcp_f32 (each ~1 ulp), ~3e-7 relative
-            return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-        case HIPETS_ACT_RELU: return fmaxf(x, 0.0f);
-        case HIPETS_ACT_LEAKY_RELU: return x > 0.0f ? x : slope * x;
-        case HIPETS_ACT_TANH: return tanhf(x);
-        default: return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-    }
-}
-
 }  // namespace hipets

@@ -73,7 +73,7 @@ struct hipets_engine {
     // rollout workspace
     DevBuf s0, state, totals, term, schedule;
     // plan workspace
-    DevBuf mu, disp, population, values, best_value, best_solution, lower_tmp;
+    DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -220,7 +220,7 @@ void hipets_destroy(hipets_engine* e) {
     (void)hipSetDevice(e->device);
     for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
                       &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->mu, &e->disp, &e->population, &e->values,
-                      &e->best_value, &e->best_solution, &e->lower_tmp})
+                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -686,6 +686,133 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), (int*)nullptr);
         HCHECK(hipGetLastError());
+    }
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta,
+                     float* mean, const float* lower, const float* upper, const float* s0, int32_t P, uint64_t seed,
+                     uint64_t plan_id, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (!mean || !lower || !upper || !s0) return fail("null argument");
+    if (pop < 1 || pop > 12000) return fail("population_size %d outside [1, 12000]", pop);
+    if (H < 1 || num_iterations < 0) return fail("bad horizon/num_iterations");
+    if (A != e->md.act_dim) return fail("act_dim %d != model act_dim %d", A, e->md.act_dim);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const size_t nd = (size_t)H * A;
+    if (e->mu.ensure(nd * 4) || e->past_action.ensure((size_t)A * 4) || e->population.ensure((size_t)pop * nd * 4) ||
+        e->values.ensure((size_t)pop * 4))
+        return 1;
+    HCHECK(hipMemcpyAsync(e->mu.p, mean, nd * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, H, A, e->mu.as<float>(), mean,
+                       e->past_action.as<float>());
+    HCHECK(hipGetLastError());
+    hipets_rollout_opts ro{};
+    ro.mode = HIPETS_MODE_FAST;
+    ro.seed = seed;
+    for (int k = 0; k < num_iterations; ++k) {
+        const uint64_t sid = plan_id * (uint64_t)num_iterations + (uint64_t)k;
+        if (hipets_mppi_sample(e, pop, H, A, beta, mean, e->past_action.as<float>(), lower, upper, nullptr, seed, sid,
+                               e->population.as<float>(), stream))
+            return 1;
+        ro.stream_id = sid;
+        if (hipets_rollout(e, e->population.as<float>(), s0, pop, H, P, &ro, e->values.as<float>(), stream)) return 1;
+        if (hipets_mppi_update(e, pop, H, A, gamma, e->values.as<float>(), e->population.as<float>(), mean, stream)) return 1;
+    }
+    return 0;
+}
+
+int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
+                     float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed,
+                     uint64_t plan_id, float* out, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (!p || !x0 || !lower || !upper || !elite || !s0 || !out) return fail("null argument");
+    if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
+    if (p->horizon < 2 || p->horizon > kMaxHorizon) return fail("iCEM horizon %d outside [2, %d]", p->horizon, kMaxHorizon);
+    const int K = p->elite_num, keep = p->keep_elite_size, iters = p->num_iterations, H = p->horizon, A = p->act_dim;
+    if (K < 1 || keep < 0 || keep > K) return fail("elite_num %d / keep_elite_size %d invalid", K, keep);
+    if (p->population_size < 1 || iters < 0 || !(p->population_decay_factor > 0.0)) return fail("bad iCEM parameters");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    // population sizes (:419-431) are known up front: size the workspace for the largest
+    std::vector<int> sizes(iters);
+    int max_rows = 1;
+    for (int i = 0; i < iters; ++i) {
+        int n = (int)std::ceil(std::fmax((double)p->population_size * std::pow(p->population_decay_factor, -(double)i), 2.0 * K));
+        const int m = p->population_size_module;
+        if (m > 0 && n % m) n += m - n % m;
+        sizes[i] = n;
+        if (n + keep > kMaxPop) return fail("iCEM iteration %d evaluates %d candidates (max %d)", i, n + keep, kMaxPop);
+        max_rows = std::max(max_rows, n + keep);
+    }
+    const size_t nd = (size_t)H * A;
+    if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
+        e->population.ensure((size_t)max_rows * nd * 4) || e->values.ensure((size_t)max_rows * 4) ||
+        e->kept.ensure((size_t)std::max(keep, 1) * nd * 4) || e->elite_idx.ensure((size_t)K * 4) ||
+        e->keep_idx.ensure((size_t)std::max(keep, 1) * 4))
+        return 1;
+    hipets_cem_params cp{};
+    cp.population_size = std::max(K, 1);
+    cp.horizon = H;
+    cp.act_dim = A;
+    cp.num_iterations = iters;
+    cp.elite_num = K;
+    cp.alpha = p->alpha;
+    cp.return_mean_elites = p->return_mean_elites;
+    cp.clipped_normal = 0;  // initial variance ((ub - lb)^2) / 16 (:373) and variance (not std) refit
+    cp.unbiased_var = 0;    // :479
+    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, make_cem(&cp), x0, lower, upper,
+                       e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>());
+    HCHECK(hipGetLastError());
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
+    hipets_rollout_opts ro{};
+    ro.mode = HIPETS_MODE_FAST;
+    ro.seed = seed;
+    float* popbuf = e->population.as<float>();
+    for (int i = 0; i < iters; ++i) {
+        const int n = sizes[i];
+        const uint64_t sid = (plan_id * (uint64_t)iters + (uint64_t)i) * 4;
+        int extra = 0;
+        if (has_elite) extra = (i == iters - 1 && i != 0) ? 1 : keep;
+        if (hipets_icem_sample(e, n, H, A, p->colored_noise_exponent, e->mu.as<float>(), e->disp.as<float>(), lower, upper, nullptr,
+                               seed, sid, popbuf, stream))
+            return 1;
+        if (extra) {
+            float* tail = popbuf + (size_t)n * nd;
+            if (i == iters - 1 && i != 0) {  // :463-464
+                HCHECK(hipMemcpyAsync(tail, e->mu.p, nd * 4, hipMemcpyDeviceToDevice, st));
+            } else {
+                const int32_t* kidx = keep_idx ? keep_idx + (size_t)i * keep : e->keep_idx.as<int32_t>();
+                if (!keep_idx) {
+                    hipLaunchKernelGGL(icem_keep_select_kernel, dim3(1), dim3(256), (size_t)K * 8, st, K, keep, (unsigned long long)seed,
+                                       (unsigned long long)(sid + 2), e->keep_idx.as<int32_t>());
+                    HCHECK(hipGetLastError());
+                }
+                if (i == 0) {  // :450-462
+                    if (hipets_gather_rows(e, keep, (int32_t)nd, elite, kidx, e->kept.as<float>(), stream)) return 1;
+                    if (hipets_icem_shift(e, keep, H, A, e->kept.as<float>(), e->mu.as<float>(), e->disp.as<float>(), nullptr, seed,
+                                          sid + 1, tail, stream))
+                        return 1;
+                } else {  // :465-466
+                    if (hipets_gather_rows(e, keep, (int32_t)nd, elite, kidx, tail, stream)) return 1;
+                }
+            }
+        }
+        const int rows = n + extra;
+        ro.stream_id = sid + 3;
+        if (hipets_rollout(e, popbuf, s0, rows, H, P, &ro, e->values.as<float>(), stream)) return 1;
+        cp.population_size = rows;
+        if (check_cem(&cp)) return 1;
+        int n2 = 1;
+        while (n2 < rows) n2 <<= 1;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8, st, make_cem(&cp), e->values.as<float>(), popbuf,
+                           e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(), e->best_solution.as<float>(),
+                           e->elite_idx.as<int>());
+        HCHECK(hipGetLastError());
+        if (hipets_gather_rows(e, K, (int32_t)nd, popbuf, e->elite_idx.as<int32_t>(), elite, stream)) return 1;  // :476
+        has_elite = 1;
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;

@@ -172,6 +172,38 @@ __global__ void icem_shift_kernel(int keep, int H, int A, const float* __restric
     }
 }
 
+// MPPIOptimizer.optimize prologue (trajectory_opt.py:257-258): mean[:-1] = mean[1:] (the last row stays) and
+// past_action = the ALREADY shifted mean[0] (Appendix B5).  `src` is a private copy of the caller's mean.
+__global__ void mppi_shift_kernel(int H, int A, const float* __restrict__ src, float* __restrict__ mean, float* __restrict__ past_action) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * A) return;
+    const int t = i / A, a = i % A;
+    const float v = src[(t + 1 < H ? t + 1 : t) * A + a];
+    mean[i] = v;
+    if (t == 0) past_action[a] = v;
+}
+
+// `keep` distinct indices drawn uniformly from [0, K) in random order: the law of torch.randperm(K)[:keep]
+// (trajectory_opt.py:446-448).  One workgroup: every index gets a Philox key, its rank among the keys is its
+// position in the permutation.
+__global__ __launch_bounds__(256) void icem_keep_select_kernel(int K, int keep, unsigned long long seed, unsigned long long stream,
+                                                              int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        const Philox4 r = philox4x32_10((uint32_t)j, 0x4B454550u, 0u, (uint32_t)stream, (uint32_t)seed,
+                                        (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32) ^ 0x5EED5EEDu);
+        keys[j] = ((unsigned long long)r.x << 32) | r.y;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        const unsigned long long kj = keys[j];
+        int rank = 0;
+        for (int i = 0; i < K; ++i) rank += (keys[i] < kj) || (keys[i] == kj && i < j);
+        if (rank < keep) out[rank] = j;
+    }
+}
+
 // rows of `src` selected by `index` (int64, like torch.index_select) -> dst; used for population[elite_idx]
 __global__ void gather_rows_kernel(int rows, int D, const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

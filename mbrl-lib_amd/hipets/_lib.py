@@ -57,6 +57,15 @@ class CemParams(C.Structure):
     ]
 
 
+class IcemParams(C.Structure):
+    _fields_ = [
+        ("population_size", C.c_int32), ("horizon", C.c_int32), ("act_dim", C.c_int32),
+        ("num_iterations", C.c_int32), ("elite_num", C.c_int32), ("keep_elite_size", C.c_int32),
+        ("population_size_module", C.c_int32), ("return_mean_elites", C.c_int32), ("alpha", C.c_double),
+        ("population_decay_factor", C.c_double), ("colored_noise_exponent", C.c_double),
+    ]
+
+
 # every symbol include/hipets.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -79,6 +88,10 @@ SYMBOLS = {
     "hipets_icem_shift": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_plan_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_plan_cem_batched": (C.c_int, [_P, C.POINTER(CemParams), C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_plan_mppi": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int32,
+                                   C.c_uint64, C.c_uint64, _P]),
+    "hipets_plan_icem": (C.c_int, [_P, C.POINTER(IcemParams), _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64, C.c_uint64,
+                                   _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
     "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }

@@ -353,6 +353,51 @@ class Engine:
                                                          int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
         return out
 
+    def plan_mppi(self, pop: int, H: int, A: int, num_iterations: int, gamma: float, beta: float, mean: torch.Tensor, lower,
+                  upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0) -> torch.Tensor:
+        """Whole MPPI plan on the device (hipets_plan_mppi).  ``mean`` [H, A] is the optimizer's persistent mean: shifted
+        and refined IN PLACE; returned for convenience."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        for n_, t in (("mean", mean), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, (H, A))
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_mppi(self._h, pop, H, A, num_iterations, float(gamma), float(beta), _ptr(mean), _ptr(lower),
+                                                  _ptr(upper), s0.ctypes.data_as(C.c_void_p), num_particles,
+                                                  int(seed) & (2**64 - 1), int(plan_id) & (2**64 - 1), _stream(dev)))
+        return mean
+
+    def plan_icem(self, p: "_lib.IcemParams", x0, lower, upper, elite: torch.Tensor, has_elite: bool, s0: np.ndarray,
+                  num_particles: int, seed: int = 0, plan_id: int = 0, keep_idx: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Whole iCEM plan on the device (hipets_plan_icem).  ``elite`` [elite_num, H, A] is the optimizer's persistent
+        elite set (read when ``has_elite``, always overwritten); ``keep_idx`` int32 [num_iterations, keep] optionally
+        injects the kept-elite draws."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        _check_dev(elite, torch.float32, dev, "elite", (p.elite_num,) + shp)
+        if keep_idx is not None:
+            _check_dev(keep_idx, torch.int32, dev, "keep_idx", (p.num_iterations, p.keep_elite_size))
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_icem(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper), _ptr(elite),
+                                                  int(bool(has_elite)), _ptr(keep_idx) if keep_idx is not None else None,
+                                                  s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                  int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
     # ---- instrumentation ---------------------------------------------------------------------------
     def timing_enable(self, on: bool = True):
         _lib.check(self._lib.hipets_timing_enable(self._h, int(on)))

@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from ._lib import HipetsError
+from ._lib import HipetsError, IcemParams
 from .engine import Engine
 from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_model_env
 
@@ -337,6 +337,16 @@ def _fused_target(obj_fun) -> Optional[HipTrajectoryEvalFn]:
     return None
 
 
+def _prepare_fused(fused: HipTrajectoryEvalFn, population_sizes: Sequence[int]):
+    """What ``fused.__call__`` would do before a rollout, for plans that run as one library call: re-pack the
+    weights if the live model changed, make them the engine's current model, validate every batch size."""
+    fused.refresh()
+    for n in population_sizes:
+        fused.check_batch(int(n))
+    if fused.engine.spec is not fused.spec:
+        fused.engine.set_model(fused.spec)
+
+
 # ---------------------------------------------------------------------------------------------
 # optimizers
 # ---------------------------------------------------------------------------------------------
@@ -397,10 +407,7 @@ class CEMOptimizer(Optimizer):
         self.calls += 1
         fused = _fused_target(obj_fun) if (callback is None and x0.ndim == 2) else None
         if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
-            fused.refresh()
-            fused.check_batch(self.population_size)
-            if fused.engine.spec is not fused.spec:
-                fused.engine.set_model(fused.spec)
+            _prepare_fused(fused, [self.population_size])
             return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
                                         fused.num_particles, seed=self.seed ^ fused.seed, plan_id=self.calls)
         p = self._params
@@ -452,6 +459,13 @@ class MPPIOptimizer(Optimizer):
                  callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
         H, A, pop = self.planning_horizon, self.action_dimension, self.population_size
         self.calls += 1
+        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("noise") is None) else None
+        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+            _prepare_fused(fused, [pop])
+            self.mean = self.mean.contiguous()
+            self.engine.plan_mppi(pop, H, A, self.refinements, self.gamma, self.beta, self.mean, self.lower_bound, self.upper_bound,
+                                  obj_fun.obs, fused.num_particles, seed=self.seed ^ fused.seed, plan_id=self.calls)
+            return self.mean.clone()
         shifted = self.mean.clone()
         shifted[:-1] = self.mean[1:]  # :258
         self.mean = shifted.contiguous()
@@ -524,6 +538,27 @@ class ICEMOptimizer(Optimizer):
         H, A = x0.shape
         K, keep = int(self.elite_num), int(self.keep_elite_size)
         self.calls += 1
+        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("inject") is None) else None
+        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+            sizes = []
+            for i in range(self.num_iterations):
+                extra = 0
+                if self.elite is not None or i > 0:
+                    extra = 1 if (i == self.num_iterations - 1 and i != 0) else keep
+                sizes.append(self._iteration_size(i) + extra)
+            _prepare_fused(fused, sizes)
+            p = IcemParams(population_size=int(self.population_size), horizon=H, act_dim=A, num_iterations=int(self.num_iterations),
+                           elite_num=K, keep_elite_size=keep, population_size_module=int(self.population_size_module or 0),
+                           return_mean_elites=int(bool(self.return_mean_elites)), alpha=float(self.alpha),
+                           population_decay_factor=float(self.population_decay_factor),
+                           colored_noise_exponent=float(self.colored_noise_exponent))
+            has_elite = self.elite is not None
+            elite = self.elite.contiguous() if has_elite else torch.empty((K, H, A), device=self.device, dtype=torch.float32)
+            out = eng.plan_icem(p, x0, self.lower_bound, self.upper_bound, elite, has_elite, obj_fun.obs, fused.num_particles,
+                                seed=self.seed ^ fused.seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"))
+            if self.num_iterations > 0:
+                self.elite = elite
+            return out
         mu = x0.clone()
         var = self.initial_var.clone().contiguous()
         best_solution = torch.zeros_like(mu)

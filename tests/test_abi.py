@@ -20,7 +20,8 @@ def header_functions():
 def test_header_declares_expected_entry_points():
     fns = header_functions()
     for must in ("hipets_create", "hipets_destroy", "hipets_set_model", "hipets_rollout", "hipets_cem_sample",
-                 "hipets_cem_refit", "hipets_plan_cem", "hipets_last_error", "hipets_abi_version"):
+                 "hipets_cem_refit", "hipets_plan_cem", "hipets_plan_icem", "hipets_plan_mppi", "hipets_last_error",
+                 "hipets_abi_version"):
         assert must in fns
 
 
@@ -48,6 +49,7 @@ def test_struct_layouts_match_header_field_order():
     assert fields("hipets_model_desc") == [f[0] for f in _lib.ModelDesc._fields_]
     assert fields("hipets_rollout_opts") == [f[0] for f in _lib.RolloutOpts._fields_]
     assert fields("hipets_cem_params") == [f[0] for f in _lib.CemParams._fields_]
+    assert fields("hipets_icem_params") == [f[0] for f in _lib.IcemParams._fields_]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")

@@ -410,3 +410,71 @@ def test_exact_device_mode_has_reference_semantics(engine):
     se = torch.sqrt(dev_runs.var(0) / 12 + ref_runs.var(0) / 12)
     z = (dev_runs.mean(0) - ref_runs.mean(0)) / se
     assert z.abs().max() < 4.5 and abs(z.mean()) < 1.0
+
+
+def _deterministic_objective(engine, obs, act, H, P, members=5, elite=None):
+    """A model whose rollouts do not consume randomness (expectation propagation, deterministic head), so fused and
+    per-iteration optimizer paths can be compared bit for bit."""
+    from hipets.planning import _BoundObjective
+
+    om = po.make_synthetic_model(obs, act, ensemble_size=members, hid=48, seed=9, deterministic=True, elite=elite)
+    om.propagation = "expectation"
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=0)
+    return _BoundObjective(fn, (np.random.default_rng(3).standard_normal(obs) * 0.1).astype(np.float32))
+
+
+def test_fused_mppi_plan_equals_per_iteration_path(engine):
+    """hipets_plan_mppi is the MPPIOptimizer.optimize loop (trajectory_opt.py:238-311) enqueued by the library: same
+    kernels, same Philox streams => bitwise the same means over consecutive calls (persistent, shifted mean)."""
+    obs, act, H, P, pop = 17, 6, 9, 5, 120
+    obj = _deterministic_objective(engine, obs, act, H, P)
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    a = hipets.MPPIOptimizer(3, pop, 0.9, 1.0, 0.9, lb, ub, DEV, seed=21)
+    b = hipets.MPPIOptimizer(3, pop, 0.9, 1.0, 0.9, lb, ub, DEV, seed=21)
+    for _ in range(3):
+        fused = a.optimize(obj)
+        generic = b.optimize(obj, force_generic=True)
+        assert torch.equal(fused, generic)
+        assert torch.equal(a.mean, b.mean)
+    assert fused.abs().max() > 0 and torch.isfinite(fused).all()
+
+
+@pytest.mark.parametrize("return_mean", [True, False])
+def test_fused_icem_plan_equals_per_iteration_path(engine, return_mean):
+    """hipets_plan_icem vs the per-iteration ICEMOptimizer path with the kept-elite draws injected into both: bitwise
+    equal plans and persistent elites over two calls (first call has no elites, second shifts them, :450-462)."""
+    obs, act, H, P = 17, 6, 8, 5
+    obj = _deterministic_objective(engine, obs, act, H, P, members=7, elite=[0, 1, 2, 3, 4])
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    mk = lambda: hipets.ICEMOptimizer(4, 0.1, 150, 1.3, 2.0, lb, ub, 0.3, 0.1, DEV, return_mean_elites=return_mean,  # noqa: E731
+                                      population_size_module=5, seed=17)
+    a, b = mk(), mk()
+    K, keep = int(a.elite_num), int(a.keep_elite_size)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.zeros(H, act)
+    for call in range(2):
+        perms = [torch.randperm(K, generator=g) for _ in range(4)]
+        keep_idx = torch.stack([p_[:keep] for p_ in perms]).to(torch.int32).to(DEV).contiguous()
+        fused = a.optimize(obj, x0=x0, keep_idx=keep_idx)
+        generic = b.optimize(obj, x0=x0, inject=[{"keep_perm": p_} for p_ in perms])
+        assert torch.equal(fused, generic), call
+        assert torch.equal(a.elite, b.elite), call
+        x0 = fused.cpu()
+    assert torch.isfinite(fused).all() and (fused.abs() <= 1).all()
+
+
+def test_fused_icem_draws_its_own_kept_elites(engine):
+    """Without injected keep indices the library draws randperm(elite_num)[:keep] itself: distinct, in range."""
+    from hipets._lib import IcemParams  # noqa: F401  (struct is part of the binding)
+
+    obs, act, H, P = 17, 6, 8, 5
+    obj = _deterministic_objective(engine, obs, act, H, P)
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    opt = hipets.ICEMOptimizer(3, 0.1, 100, 1.3, 2.0, lb, ub, 0.5, 0.1, DEV, return_mean_elites=True, population_size_module=5, seed=4)
+    p1 = opt.optimize(obj, x0=torch.zeros(H, act))
+    p2 = opt.optimize(obj, x0=p1)
+    assert torch.isfinite(p2).all() and tuple(opt.elite.shape) == (int(opt.elite_num), H, act)
+    g = torch.Generator().manual_seed(1)
+    rand = (torch.rand(8, H, act, generator=g) * 2 - 1).to(DEV)
+    vals = obj(torch.cat([p2[None], rand]).contiguous())
+    assert vals[0] > vals[1:].median()  # the refined plan beats typical random plans under the same deterministic model
