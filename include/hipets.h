@@ -49,6 +49,11 @@ enum { HIPETS_TERM_NONE = 0, HIPETS_TERM_CARTPOLE = 1, HIPETS_TERM_INVERTED_PEND
        HIPETS_TERM_WALKER2D = 4, HIPETS_TERM_ANT = 5, HIPETS_TERM_HUMANOID = 6 };
 /* Normalizer dtype (mbrl/util/math.py:108-111; normalize_double_precision, one_dim_tr_model.py:87-92) */
 enum { HIPETS_NORM_NONE = 0, HIPETS_NORM_F32 = 1, HIPETS_NORM_F64 = 2 };
+/* Ensemble container: GAUSSIAN_MLP = one GaussianMLP with E members: balanced random shuffles and the batch % members
+ * check (mbrl/models/gaussian_mlp.py:179-216); BASIC_ENSEMBLE = mbrl.models.BasicEnsemble of E single-member
+ * GaussianMLPs (conf/dynamics_model/basic_ensemble.yaml): every row draws its member independently
+ * (basic_ensemble.py:122-129, 255-260), any batch size, no elites (:262-266), per-member logvar bounds. */
+enum { HIPETS_ENSEMBLE_GAUSSIAN_MLP = 0, HIPETS_ENSEMBLE_BASIC = 1 };
 /* randomness source of a rollout */
 enum { HIPETS_MODE_EXACT = 0, /* reference semantics, injected perms / eps (parity mode)      */
        HIPETS_MODE_FAST = 1   /* whole-horizon persistent kernel, in-kernel Philox (fast mode) */ };
@@ -82,10 +87,11 @@ typedef struct {
     int32_t normalizer;      /* HIPETS_NORM_*                                                     */
     const double* norm_mean; /* HOST [in_dim] (f32 stats widened exactly; arithmetic stays f32)   */
     const double* norm_std;  /* HOST [in_dim]                                                     */
-    const float* min_logvar; /* HOST [out_dim] or NULL if deterministic                           */
-    const float* max_logvar; /* HOST [out_dim]                                                    */
+    const float* min_logvar; /* HOST [out_dim] ([M,out_dim] for BASIC_ENSEMBLE: every member owns */
+    const float* max_logvar; /*   its bounds) or NULL if deterministic                            */
     const void* const* weights; /* HOST array [n_layers] of DEVICE float [E, in_l, out_l]         */
     const void* const* biases;  /* HOST array [n_layers] of DEVICE float [E, 1, out_l]            */
+    int32_t ensemble_kind;   /* HIPETS_ENSEMBLE_*                                                 */
 } hipets_model_desc;
 
 /* options of one evaluate_action_sequences call */
@@ -108,6 +114,9 @@ typedef struct {
     int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
                              /*   workgroup 0, accumulated (profiling aid)                */
     int32_t no_sample;       /* FAST: predictions are the mean (no eps), like ModelEnv.step(sample=False) */
+    int32_t rows_per_member; /* EXACT, BASIC_ENSEMBLE only: perms is [H, M*rows_per_member] ([M*rows_per_member] for  */
+                             /*   fixed_model): slot m*rows_per_member + j = j-th row of member m, -1 = padding        */
+                             /*   (members own unequal row counts under randint, basic_ensemble.py:122-129)            */
     int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
                              /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
 } hipets_rollout_opts;

@@ -124,7 +124,7 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
 size_t lds_for(const hipets_engine* e, int R, int horizon) {
     const ModelDev& md = e->md;
     return rollout_smem_bytes(kTile * R, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, horizon,
-                              md.propagation == HIPETS_PROP_EXPECTATION);
+                              md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows);
 }
 
 // cost model for the row-tile count R of a workgroup: (sequential workgroup rounds per CU) x (MFMA units
@@ -245,6 +245,11 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     if ((d->obs_process == HIPETS_OBS_HALFCHEETAH) && d->obs_dim < 3) return fail("halfcheetah obs_process needs obs_dim >= 3");
     if (d->obs_dim < 2 && (d->termination_fn != HIPETS_TERM_NONE || d->reward_fn == HIPETS_REW_CARTPOLE_PETS)) return fail("termination/reward fn needs obs_dim >= 2");
     if (!d->deterministic && (!d->min_logvar || !d->max_logvar)) return fail("logvar bounds missing");
+    if (d->ensemble_kind != HIPETS_ENSEMBLE_GAUSSIAN_MLP && d->ensemble_kind != HIPETS_ENSEMBLE_BASIC)
+        return fail("unknown ensemble_kind %d", d->ensemble_kind);
+    if (d->ensemble_kind == HIPETS_ENSEMBLE_BASIC && d->n_members != d->ensemble_size)
+        return fail("BasicEnsemble has no elite subset (basic_ensemble.py:262-266): n_members %d != ensemble_size %d", d->n_members,
+                    d->ensemble_size);
     if (d->normalizer != HIPETS_NORM_NONE && (!d->norm_mean || !d->norm_std)) return fail("normalizer stats missing");
     for (int i = 0; i < d->n_members; ++i)
         if (d->members[i] < 0 || d->members[i] >= d->ensemble_size) return fail("member index %d out of range", d->members[i]);
@@ -257,6 +262,8 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     md.deterministic = d->deterministic; md.obs_process = d->obs_process; md.reward_fn = d->reward_fn;
     md.term_fn = d->termination_fn; md.target_is_delta = d->target_is_delta; md.learned_rewards = d->learned_rewards;
     md.normalizer = d->normalizer;
+    md.iid_members = d->ensemble_kind == HIPETS_ENSEMBLE_BASIC ? 1 : 0;
+    md.lv_rows = (md.iid_members && !d->deterministic) ? d->n_members : 1;
     auto up16 = [](int x) { return (x + 15) / 16 * 16; };
     long long woff = 0;
     int boff = 0, maxK = 0;
@@ -283,7 +290,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     while (ld % 64 != 8) ld += 4;
     md.ld = ld;
     if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, 64,
-                           md.propagation == HIPETS_PROP_EXPECTATION) > e->lds_max)
+                           md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows) > e->lds_max)
         return fail("model too wide for LDS (ld=%d)", md.ld);
 
     if (e->wpack.ensure((size_t)md.wmember * md.M * 4)) return 1;
@@ -310,9 +317,10 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         HCHECK(hipMemcpyAsync(e->norm_std.p, d->norm_std, (size_t)d->in_dim * 8, hipMemcpyHostToDevice, st));
     }
     if (!d->deterministic) {
-        if (e->min_lv.ensure((size_t)d->out_dim * 4) || e->max_lv.ensure((size_t)d->out_dim * 4)) return 1;
-        HCHECK(hipMemcpyAsync(e->min_lv.p, d->min_logvar, (size_t)d->out_dim * 4, hipMemcpyHostToDevice, st));
-        HCHECK(hipMemcpyAsync(e->max_lv.p, d->max_logvar, (size_t)d->out_dim * 4, hipMemcpyHostToDevice, st));
+        const size_t nlv = (size_t)md.lv_rows * d->out_dim * 4;
+        if (e->min_lv.ensure(nlv) || e->max_lv.ensure(nlv)) return 1;
+        HCHECK(hipMemcpyAsync(e->min_lv.p, d->min_logvar, nlv, hipMemcpyHostToDevice, st));
+        HCHECK(hipMemcpyAsync(e->max_lv.p, d->max_logvar, nlv, hipMemcpyHostToDevice, st));
     }
     std::vector<unsigned char> nd(d->obs_dim, 0);
     for (int i = 0; i < d->n_no_delta; ++i) {
@@ -385,13 +393,15 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     if (o->mode == HIPETS_MODE_EXACT) {
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
-        if (B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
+        if (!md.iid_members && B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
             return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
                         "Current batch size is %lld for %d models.", B, md.M);
         if (!expectation) {
             if (!o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
+            if (md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
+                return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
         }
-        const int rpd = (int)(B / domains);
+        const int rpd = expectation ? (int)B : (md.iid_members ? o->rows_per_member : (int)(B / domains));
         const long long tiles = (rpd + kTile - 1) / kTile;
         const int R = choose_R(e, tiles, domains, o->rows_per_group, H);
         const size_t lds = lds_for(e, R, H);
@@ -407,7 +417,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         ra.state = e->state.as<float>();
         ra.term = e->term.as<unsigned char>();
         ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
-        ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? B : 0;
+        ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? (long long)domains * rpd : 0;
         ra.eps = o->eps;
         ra.use_philox = 0;
         for (int t = 0; t < H; ++t) {
@@ -432,7 +442,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
             } else {
                 if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
                 hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
-                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)o->seed,
+                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
                                    (unsigned long long)o->stream_id);
                 HCHECK(hipGetLastError());
                 ra.schedule = e->schedule.as<int>();
@@ -458,7 +468,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     HCHECK(hipSetDevice(e->device));
     const ModelDev& md = e->md;
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
-    if (B % md.M != 0)  // gaussian_mlp.py:195-200
+    if (!md.iid_members && B % md.M != 0)  // gaussian_mlp.py:195-200
         return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
                     "Current batch size is %d for %d models.", B, md.M);
     // the kernel updates state / totals / terminated in place: run it on the caller's output buffers
@@ -484,7 +494,9 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
         if (!expectation && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
-        const int rpd = B / domains;
+        if (!expectation && md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
+            return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
+        const int rpd = expectation ? B : (md.iid_members ? o->rows_per_member : B / domains);
         const long long tiles = (rpd + kTile - 1) / kTile;
         const int R = choose_R(e, tiles, domains, o->rows_per_group, 1);
         const size_t lds = lds_for(e, R, 1);
@@ -514,7 +526,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
             } else {
                 if (e->schedule.ensure((size_t)nwg * 4)) return 1;
                 hipLaunchKernelGGL(member_schedule_kernel, dim3(1), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
-                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)o->seed,
+                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
                                    (unsigned long long)o->stream_id);
                 HCHECK(hipGetLastError());
                 ra.schedule = e->schedule.as<int>();
@@ -533,7 +545,7 @@ int hipets_fast_schedule(hipets_engine* e, int32_t H, int32_t nwg, uint64_t seed
     if (!schedule || H < 1 || nwg < 1) return fail("bad argument");
     HCHECK(hipSetDevice(e->device));
     hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
-                       e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, (unsigned long long)seed,
+                       e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, e->md.iid_members, (unsigned long long)seed,
                        (unsigned long long)stream_id);
     HCHECK(hipGetLastError());
     return 0;

@@ -53,8 +53,10 @@ struct ModelDev {
     const float* b;
     const double* norm_mean;
     const double* norm_std;
-    const float* min_lv;
+    const float* min_lv;  // [lv_rows][out_dim]
     const float* max_lv;
+    int lv_rows;          // 1 (bounds shared by the members) or M (BasicEnsemble: one row per member)
+    int iid_members;      // BasicEnsemble: members are drawn independently (no balanced shuffle, no batch % M rule)
     const unsigned char* no_delta;  // [obs_dim]
 };
 
@@ -458,8 +460,8 @@ struct RolloutSmem {
     int* rowid;      // [ROWS] global row id (candidate*P + particle) or -1
     double* nmean;   // [in_dim] normaliser stats (f64 like the reference)
     double* nstd;    // [in_dim]
-    float* minlv;    // [out_dim]
-    float* maxlv;    // [out_dim]
+    float* minlv;    // [lv_rows][out_dim]
+    float* maxlv;    // [lv_rows][out_dim]
     int* nodelta;    // [obs_dim]
     int* sched;      // [H] member slot of this workgroup per step (FAST)
     LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
@@ -469,14 +471,14 @@ struct RolloutSmem {
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_dim, int act_dim, int in_dim, int out_dim,
-                                                     int out_total, int horizon, bool expectation) {
+                                                     int out_total, int horizon, bool expectation, int lv_rows = 1) {
     size_t n = 0;
     n += 2 * align16((size_t)rows * ld * 4);
     n += align16((size_t)rows * obs_dim * 4);
     n += align16((size_t)2 * rows * act_dim * 4);
     n += 4 * align16((size_t)rows * 4);
     n += 2 * align16((size_t)in_dim * 8);
-    n += 2 * align16((size_t)out_dim * 4);
+    n += 2 * align16((size_t)lv_rows * out_dim * 4);
     n += align16((size_t)obs_dim * 4);
     n += align16((size_t)horizon * 4);
     n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
@@ -510,8 +512,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         sm.rowid = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
         sm.nmean = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
         sm.nstd = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
-        sm.minlv = reinterpret_cast<float*>(p); p += align16((size_t)md.out_dim * 4);
-        sm.maxlv = reinterpret_cast<float*>(p); p += align16((size_t)md.out_dim * 4);
+        sm.minlv = reinterpret_cast<float*>(p); p += align16((size_t)md.lv_rows * md.out_dim * 4);
+        sm.maxlv = reinterpret_cast<float*>(p); p += align16((size_t)md.lv_rows * md.out_dim * 4);
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
@@ -538,6 +540,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         domain = wg / ra.groups;
         const int j0 = (wg % ra.groups) * ROWS;
         const long long* perm = ra.perm ? ra.perm + (long long)ra.t_begin * ra.perm_step : nullptr;
+        // unbalanced member maps (BasicEnsemble) pad every member's slots with -1 at the tail: nothing to do here
+        if (perm && perm[(long long)domain * ra.rows_per_domain + j0] < 0) return;
         for (int s = tid; s < ROWS; s += kThreads) {
             const int j = j0 + s;
             int rid = -1;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     if (md.normalizer != HIPETS_NORM_NONE)
         for (int i = tid; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = md.norm_std[i]; }
     if (!md.deterministic)
-        for (int i = tid; i < md.out_dim; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
+        for (int i = tid; i < md.lv_rows * md.out_dim; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
     for (int i = tid; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
     for (int i = tid; i < md.n_layers; i += kThreads) sm.lmeta[i] = md.layers[i];
     __syncthreads();
@@ -689,8 +693,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
     for (int t = ra.t_begin; t < ra.t_end; ++t) {
         const int n_run = expectation ? md.M : 1;
         float* result = nullptr;
+        int member = 0;
         for (int mi = 0; mi < n_run; ++mi) {
-            int member;
             if (expectation) member = mi;
             else if (fast) member = sm.sched[t];
             else member = domain;
@@ -716,8 +720,9 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                     float v = result[s * md.ld + c];
                     if (!md.deterministic && c >= md.out_dim) {
                         const int d = c - md.out_dim;
-                        v = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - v);
-                        v = sm.minlv[d] + softplus_fast(v - sm.minlv[d]);
+                        const int bd = (md.lv_rows > 1 ? member * md.out_dim : 0) + d;
+                        v = sm.maxlv[bd] - softplus_fast(sm.maxlv[bd] - v);
+                        v = sm.minlv[bd] + softplus_fast(v - sm.minlv[bd]);
                     }
                     sm.expacc[i] = mi == 0 ? v : sm.expacc[i] + v;
                 }
@@ -736,6 +741,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             constexpr bool EXPECT = decltype(expect_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
             const float inv_m = 1.0f / (float)md.M;
+            const float* lvmin = sm.minlv + (md.lv_rows > 1 ? member * md.out_dim : 0);  // this step's member owns the bounds
+            const float* lvmax = sm.maxlv + (md.lv_rows > 1 ? member * md.out_dim : 0);
             for (int item = tid; item < ROWS * nblk; item += kThreads) {
                 const int s = item / nblk, blk = item % nblk;
                 const int rid = sm.rowid[s];
@@ -762,8 +769,8 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
                         mean = result[s * md.ld + d];
                         if constexpr (MODE != 0) {
                             lv = result[s * md.ld + md.out_dim + d];
-                            lv = sm.maxlv[d] - softplus_fast(sm.maxlv[d] - lv);  // gaussian_mlp.py:152
-                            lv = sm.minlv[d] + softplus_fast(lv - sm.minlv[d]);  // :153
+                            lv = lvmax[d] - softplus_fast(lvmax[d] - lv);  // gaussian_mlp.py:152
+                            lv = lvmin[d] + softplus_fast(lv - lvmin[d]);  // :153
                         }
                     }
                     if constexpr (MODE != 0) pred[q] = mean + __builtin_amdgcn_sqrtf(exp_hw(lv)) * nrm[q];  // model.py:471-473
@@ -860,7 +867,9 @@ __global__ void particle_mean_kernel(const float* totals, float* returns, int po
 // (every slot gets floor/ceil(nWG/M) workgroups -- the reference's "each model gets exactly the same
 // number of samples", gaussian_mlp.py:267-275, at 16*R-row granularity).  fixed_model: one draw
 // for all steps (TS-infinity).  One block per step.
-__global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, unsigned long long seed,
+// BasicEnsemble (iid != 0): every workgroup draws its slot independently and uniformly (randint,
+// basic_ensemble.py:122-129), no balancing.
+__global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, int iid, unsigned long long seed,
                                        unsigned long long stream_id) {
     extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
     const int t = blockIdx.x;
@@ -868,6 +877,11 @@ __global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, un
     const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
     for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
     __syncthreads();
+    if (iid) {
+        for (int me = threadIdx.x; me < nwg; me += blockDim.x)
+            sched[(size_t)t * nwg + me] = (int)(((keys[me] >> 32) * (unsigned long long)M) >> 32);
+        return;
+    }
     for (int me = threadIdx.x; me < nwg; me += blockDim.x) {
         const unsigned long long kme = keys[me];
         int rank = 0;

@@ -17,6 +17,7 @@ OBS = {"none": 0, "halfcheetah": 1, "cartpole_pets": 2}
 REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendulum": 3, "halfcheetah": 4, "pusher": 5, "none": 6}
 TERM = {"no_termination": 0, "cartpole": 1, "inverted_pendulum": 2, "hopper": 3, "walker2d": 4, "ant": 5, "humanoid": 6}
 NORM = {"none": 0, "f32": 1, "f64": 2}
+ENSEMBLE = {"gaussian_mlp": 0, "basic_ensemble": 1}
 MODE_EXACT, MODE_FAST = 0, 1
 
 
@@ -32,6 +33,7 @@ class ModelDesc(C.Structure):
         ("normalizer", C.c_int32), ("norm_mean", C.POINTER(C.c_double)), ("norm_std", C.POINTER(C.c_double)),
         ("min_logvar", C.POINTER(C.c_float)), ("max_logvar", C.POINTER(C.c_float)),
         ("weights", C.POINTER(C.c_void_p)), ("biases", C.POINTER(C.c_void_p)),
+        ("ensemble_kind", C.c_int32),
     ]
 
 
@@ -45,6 +47,7 @@ class RolloutOpts(C.Structure):
         ("rows_per_group", C.c_int32),
         ("phase_cycles", C.c_void_p),
         ("no_sample", C.c_int32),
+        ("rows_per_member", C.c_int32),
         ("n_env", C.c_int32),
     ]
 

@@ -34,6 +34,24 @@ def _check_dev(t: torch.Tensor, dtype, device, name: str, shape=None, numel=None
         raise ValueError(f"{name} must have {numel} elements, got {t.numel()}")
 
 
+def member_slots(members: torch.Tensor, n_members: int, device) -> tuple:
+    """Row -> member map(s) ``members`` int64 [T, B] -> (slots int64 [T, M * rpm] on ``device``, rpm): slot m * rpm + j holds
+    the j-th row (ascending) of member m, -1 pads the tail (hipets_rollout_opts.rows_per_member).  Pure index plumbing
+    with torch ops on whichever device ``members`` lives: a CPU map gets the tight rpm = largest member count; a device
+    map uses rpm = B so that no count has to travel to the host (all-padding workgroups exit immediately)."""
+    T, B = members.shape
+    members = members.to(torch.int64)
+    counts = torch.zeros(T, n_members, dtype=torch.int64, device=members.device).scatter_add_(1, members, torch.ones_like(members))
+    rpm = int(counts.max()) if members.device.type == "cpu" else B
+    order = members.argsort(dim=1, stable=True)
+    sorted_m = members.gather(1, order)
+    starts = counts.cumsum(1) - counts
+    pos = torch.arange(B, device=members.device).unsqueeze(0) - starts.gather(1, sorted_m)
+    slots = torch.full((T, n_members * rpm), -1, dtype=torch.int64, device=members.device)
+    slots.scatter_(1, sorted_m * rpm + pos, order)
+    return slots.to(device).contiguous(), max(rpm, 1)
+
+
 class Engine:
     """One fused planning engine bound to ``device`` (a gfx950 GPU).  Not thread-safe."""
 
@@ -94,9 +112,15 @@ class Engine:
             d.norm_std = ns.ctypes.data_as(C.POINTER(C.c_double))
         else:
             d.normalizer = _lib.NORM["none"]
+        basic = spec.ensemble_kind == "basic_ensemble"
+        d.ensemble_kind = _lib.ENSEMBLE[spec.ensemble_kind]
         if not spec.deterministic:
-            lo = np.ascontiguousarray(spec.min_logvar.detach().cpu().float().numpy().reshape(-1))
-            hi = np.ascontiguousarray(spec.max_logvar.detach().cpu().float().numpy().reshape(-1))
+            lo_t, hi_t = spec.min_logvar.detach().cpu().float(), spec.max_logvar.detach().cpu().float()
+            if basic:  # every member owns its bounds: [M, out] (a shared [1, out] is broadcast)
+                lo_t = lo_t.reshape(-1, spec.out_dim).expand(len(members), spec.out_dim)
+                hi_t = hi_t.reshape(-1, spec.out_dim).expand(len(members), spec.out_dim)
+            lo = np.ascontiguousarray(lo_t.numpy().reshape(-1))
+            hi = np.ascontiguousarray(hi_t.numpy().reshape(-1))
             d.min_logvar = lo.ctypes.data_as(C.POINTER(C.c_float))
             d.max_logvar = hi.ctypes.data_as(C.POINTER(C.c_float))
         w_arr = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
@@ -112,7 +136,10 @@ class Engine:
                 stream_id: int = 0, member_schedule: Optional[torch.Tensor] = None,
                 trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
                 rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
-                phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1) -> torch.Tensor:
+                phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1,
+                members: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``members`` (EXACT mode, BasicEnsemble models): int64 [H, B] (random_model) or [B] (fixed_model) member of every
+        row, i.e. the reference's ``torch.randint`` draws (basic_ensemble.py:122-129, 255-260)."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -133,7 +160,14 @@ class Engine:
         o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
-        if perms is not None:
+        if members is not None:
+            if self.spec.ensemble_kind != "basic_ensemble" or mode != "exact" or perms is not None:
+                raise ValueError("members= is the EXACT-mode input of BasicEnsemble models (GaussianMLP takes perms=)")
+            want = (B,) if self.spec.propagation == "fixed_model" else (H, B)
+            if tuple(members.shape) != want:
+                raise ValueError(f"members must have shape {want}")
+            perms, o.rows_per_member = member_slots(members.reshape(-1, B), len(self.spec.members), dev)
+        elif perms is not None:
             _check_dev(perms, torch.int64, dev, "perms")
             want = (B,) if self.spec.propagation == "fixed_model" else (H, B)
             if tuple(perms.shape) != want:
@@ -170,9 +204,11 @@ class Engine:
 
     def step(self, obs: torch.Tensor, actions: torch.Tensor, *, mode: str = "fast", sample: bool = True,
              perm: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, seed: int = 0, stream_id: int = 0,
-             member_schedule: Optional[torch.Tensor] = None, rows_per_group: int = 0):
+             member_schedule: Optional[torch.Tensor] = None, rows_per_group: int = 0,
+             members: Optional[torch.Tensor] = None):
         """One model transition for B independent rows (ModelEnv.step, mbrl/models/model_env.py:87-140).
-        Returns (next_obs [B,obs], rewards [B,1], dones [B,1] bool) on the device."""
+        Returns (next_obs [B,obs], rewards [B,1], dones [B,1] bool) on the device.  ``members`` int64 [B]: EXACT-mode
+        member of every row for BasicEnsemble models (GaussianMLP models take ``perm``)."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -185,7 +221,12 @@ class Engine:
         o.rows_per_group = int(rows_per_group)
         o.no_sample = int(not sample)
         if mode == "exact":
-            if perm is not None:
+            if members is not None:
+                if self.spec.ensemble_kind != "basic_ensemble" or perm is not None or tuple(members.shape) != (B,):
+                    raise ValueError("members= must be int64 [B] and the model a BasicEnsemble (GaussianMLP takes perm=)")
+                perm, o.rows_per_member = member_slots(members.reshape(1, B), len(self.spec.members), dev)
+                o.perms = _ptr(perm)
+            elif perm is not None:
                 _check_dev(perm, torch.int64, dev, "perm", (B,))
                 o.perms = _ptr(perm)
             if sample and not self.spec.deterministic:

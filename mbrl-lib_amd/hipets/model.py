@@ -49,6 +49,11 @@ class ModelSpec:
     termination: str = "no_termination"
     custom_reward_fn: Optional[object] = None  # arbitrary torch callables (act, next_obs) -> [B,1]; UNFUSED path only
     custom_termination_fn: Optional[object] = None
+    # "gaussian_mlp": one GaussianMLP with E members (balanced shuffles, batch % members rule, elites).
+    # "basic_ensemble": mbrl.models.BasicEnsemble of E single-member GaussianMLPs: every row draws its member
+    #   independently from the generator (basic_ensemble.py:122-129, 255-260), any batch size, no elites,
+    #   min/max_logvar are [E, out] (every member owns its bounds).
+    ensemble_kind: str = "gaussian_mlp"
 
     # ---- derived ---------------------------------------------------------------------------
     @property
@@ -70,7 +75,7 @@ class ModelSpec:
 
     @property
     def members(self) -> List[int]:
-        if self.elite_models is not None:
+        if self.elite_models is not None and self.ensemble_kind != "basic_ensemble":  # basic_ensemble.py:262-266
             return [int(i) for i in self.elite_models]
         return list(range(self.ensemble_size))
 
@@ -79,6 +84,8 @@ class ModelSpec:
         return 2 * sum(int(w.shape[1]) * int(w.shape[2]) for w in self.weights)
 
     def validate(self):
+        if self.ensemble_kind not in ("gaussian_mlp", "basic_ensemble"):
+            raise UnsupportedModelError(f"ensemble kind {self.ensemble_kind!r} has no fused implementation")
         if self.activation not in _ACT_BY_CLASS.values():
             raise UnsupportedModelError(f"activation {self.activation!r} has no fused implementation")
         if self.propagation not in ("random_model", "fixed_model", "expectation"):
@@ -109,20 +116,12 @@ def _fn_name(fn) -> Optional[str]:
     return getattr(fn, "__name__", None)
 
 
-def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optional[int] = None,
-                        allow_custom_fns: bool = False) -> ModelSpec:
-    """Read a live ``mbrl.models.ModelEnv`` (or anything shaped like it).  No copy of the big tensors:
-    the spec holds references to the live parameters; ``Engine.set_model`` packs them on device.
-
-    ``allow_custom_fns``: a ``reward_fn`` / ``termination_fn`` that is not one of mbrl.env's closed forms is kept as a
-    Python callable (``spec.custom_reward_fn`` / ``spec.custom_termination_fn``) for the UNFUSED path (the model
-    transition stays fused, the callables run as torch ops between steps) instead of raising."""
-    dm = model_env.dynamics_model
-    mlp = getattr(dm, "model", None)
-    if mlp is None or not hasattr(mlp, "hidden_layers") or not hasattr(mlp, "mean_and_logvar"):
-        raise UnsupportedModelError("dynamics_model.model is not a GaussianMLP-shaped ensemble")
+def _read_gaussian_mlp(mlp):
+    """(weights, biases, activation, leaky_slope, deterministic, min_logvar, max_logvar) of a live GaussianMLP
+    (mbrl/models/gaussian_mlp.py:69-127); tensors are references to the live parameters."""
     ws, bs = [], []
     act_name = None
+    slope = 0.01
     for layer in mlp.hidden_layers:
         lin, act = layer[0], layer[1]
         if not getattr(lin, "use_bias", True):
@@ -141,6 +140,40 @@ def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optio
     if ws[0].ndim != 3:
         raise UnsupportedModelError("expected ensemble weights [E, in, out]")
     deterministic = bool(getattr(mlp, "deterministic", False))
+    lo = None if deterministic else mlp.min_logvar.detach()
+    hi = None if deterministic else mlp.max_logvar.detach()
+    return ws, bs, act_name, slope, deterministic, lo, hi
+
+
+def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optional[int] = None,
+                        allow_custom_fns: bool = False) -> ModelSpec:
+    """Read a live ``mbrl.models.ModelEnv`` (or anything shaped like it).  No copy of the big tensors:
+    the spec holds references to the live parameters; ``Engine.set_model`` packs them on device.
+
+    ``allow_custom_fns``: a ``reward_fn`` / ``termination_fn`` that is not one of mbrl.env's closed forms is kept as a
+    Python callable (``spec.custom_reward_fn`` / ``spec.custom_termination_fn``) for the UNFUSED path (the model
+    transition stays fused, the callables run as torch ops between steps) instead of raising."""
+    dm = model_env.dynamics_model
+    mlp = getattr(dm, "model", None)
+    ensemble_kind = "gaussian_mlp"
+    if mlp is not None and hasattr(mlp, "members") and not hasattr(mlp, "hidden_layers"):
+        # mbrl.models.BasicEnsemble (basic_ensemble.py:59-81): E members built from member_cfg; the fused engine takes the
+        # conf/dynamics_model/basic_ensemble.yaml shape, i.e. single-member GaussianMLPs, stacked into one [E, in, out] set
+        parts = [_read_gaussian_mlp(m) for m in mlp.members]
+        if any(p[0][0].shape[0] != 1 for p in parts):
+            raise UnsupportedModelError("BasicEnsemble members must be single-member GaussianMLPs")
+        if any(p[2:5] != parts[0][2:5] for p in parts[1:]):
+            raise UnsupportedModelError("BasicEnsemble members differ in activation / determinism")
+        ws = [torch.cat([p[0][i] for p in parts], dim=0) for i in range(len(parts[0][0]))]
+        bs = [torch.cat([p[1][i] for p in parts], dim=0) for i in range(len(parts[0][1]))]
+        act_name, slope, deterministic = parts[0][2:5]
+        lv_lo = None if deterministic else torch.cat([p[5] for p in parts], dim=0)  # [E, out]: per-member bounds
+        lv_hi = None if deterministic else torch.cat([p[6] for p in parts], dim=0)
+        ensemble_kind = "basic_ensemble"
+    elif mlp is None or not hasattr(mlp, "hidden_layers") or not hasattr(mlp, "mean_and_logvar"):
+        raise UnsupportedModelError("dynamics_model.model is not a GaussianMLP-shaped ensemble")
+    else:
+        ws, bs, act_name, slope, deterministic, lv_lo, lv_hi = _read_gaussian_mlp(mlp)
     norm = getattr(dm, "input_normalizer", None)
     obs_fn = getattr(dm, "obs_process_fn", None)
     obs_process = "none"
@@ -164,8 +197,7 @@ def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optio
             custom_term, term_name = model_env.termination_fn, "no_termination"
     spec = ModelSpec(
         weights=ws, biases=bs, obs_dim=od, act_dim=ad,
-        min_logvar=None if deterministic else mlp.min_logvar.detach(),
-        max_logvar=None if deterministic else mlp.max_logvar.detach(),
+        min_logvar=lv_lo, max_logvar=lv_hi, ensemble_kind=ensemble_kind,
         elite_models=list(mlp.elite_models) if getattr(mlp, "elite_models", None) is not None else None,
         activation=act_name or "relu", leaky_slope=slope,
         propagation=mlp.propagation_method, deterministic=deterministic,

@@ -106,6 +106,16 @@ class HipTrajectoryEvalFn:
             B = pop * self.num_particles
             g = self._device_rng()
             perms = eps = None
+            if self.spec.ensemble_kind == "basic_ensemble":  # iid randint member maps (basic_ensemble.py:122-129, 255-260)
+                members = None
+                M = len(self.spec.members)
+                if self.spec.propagation == "random_model":
+                    members = torch.randint(M, (H, B), device=self.device, generator=g)
+                elif self.spec.propagation == "fixed_model":
+                    members = torch.randint(M, (B,), device=self.device, generator=g)
+                if not self.spec.deterministic:
+                    eps = torch.randn(H, B, self.spec.out_dim, device=self.device, generator=g)
+                return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", members=members, eps=eps)
             if self.spec.propagation == "random_model":
                 perms = torch.rand(H, B, device=self.device, generator=g).argsort(dim=1)
             elif self.spec.propagation == "fixed_model":
@@ -119,6 +129,21 @@ class HipTrajectoryEvalFn:
         pop, H, _ = a.shape
         B = pop * self.num_particles
         perms = eps = None
+        if self.spec.ensemble_kind == "basic_ensemble":
+            # BasicEnsemble draws its member maps with randint FROM THE GENERATOR (basic_ensemble.py:122-129, 255-260):
+            # reset -> [fixed_model map], then per step [random_model map], normal
+            rng, M = self._cpu_rng(), len(self.spec.members)
+            members = torch.randint(M, (B,), generator=rng) if self.spec.propagation == "fixed_model" else None
+            m_list, e_list = [], []
+            for _ in range(H):
+                if self.spec.propagation == "random_model":
+                    m_list.append(torch.randint(M, (B,), generator=rng))
+                if not self.spec.deterministic:
+                    e_list.append(torch.empty(B, self.spec.out_dim).normal_(0.0, 1.0, generator=rng))
+            if m_list:
+                members = torch.stack(m_list)
+            eps = torch.stack(e_list).to(self.device) if e_list else None
+            return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", members=members, eps=eps)
         if self.spec.propagation == "fixed_model":
             perms = torch.randperm(B).to(self.device)  # gaussian_mlp.py:375 at reset
         if self.spec.propagation == "random_model" or not self.spec.deterministic:
@@ -138,6 +163,8 @@ class HipTrajectoryEvalFn:
         """The reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method and kept in
         FAST mode too so that switching engines never changes which configurations are accepted."""
         B, M = pop * self.num_particles, len(self.spec.members)
+        if self.spec.ensemble_kind == "basic_ensemble":  # BasicEnsemble.forward has no such rule (basic_ensemble.py:142-196)
+            return
         if B % M != 0:
             raise ValueError(
                 f"GaussianMLP ensemble requires batch size to be a multiple of the "
@@ -170,6 +197,7 @@ class ModelEnv:
         self._return_as_np = True
         self._steps = 0
         self._fixed_perm = None
+        self._fixed_members = None
         self._fixed_schedule = None
 
     @property
@@ -186,7 +214,11 @@ class ModelEnv:
         self._eval.num_particles = 1
         self._eval.check_batch(B)
         self._fixed_perm = self._fixed_schedule = None
+        self._fixed_members = None
         if self.spec.propagation == "fixed_model":  # model.py:404-407 -> gaussian_mlp.py:363-375
+            if self.mode == "exact" and self.spec.ensemble_kind == "basic_ensemble":  # basic_ensemble.py:255-260
+                self._fixed_members = torch.randint(len(self.spec.members), (B,), generator=self._eval._cpu_rng())
+                return {"obs": obs, "propagation_indices": self._fixed_members}
             if self.mode == "exact":
                 self._fixed_perm = torch.randperm(B).to(self.device)
             else:
@@ -209,14 +241,18 @@ class ModelEnv:
         B = obs.shape[0]
         self._steps += 1
         if self.mode == "exact":
-            perm = eps = None
+            perm = eps = members = None
+            basic = self.spec.ensemble_kind == "basic_ensemble"
             if self.spec.propagation == "random_model":
-                perm = torch.randperm(B).to(self.device)  # gaussian_mlp.py:205 (global RNG)
+                if basic:  # basic_ensemble.py:122-129 (the generator, before this step's normal)
+                    members = torch.randint(len(self.spec.members), (B,), generator=self._eval._cpu_rng())
+                else:
+                    perm = torch.randperm(B).to(self.device)  # gaussian_mlp.py:205 (global RNG)
             elif self.spec.propagation == "fixed_model":
-                perm = self._fixed_perm
+                perm, members = self._fixed_perm, self._fixed_members
             if sample and not self.spec.deterministic:
                 eps = torch.empty(B, self.spec.out_dim).normal_(0.0, 1.0, generator=self._eval._cpu_rng()).to(self.device)
-            nobs, rew, done = self.engine.step(obs, actions, mode="exact", sample=sample, perm=perm, eps=eps)
+            nobs, rew, done = self.engine.step(obs, actions, mode="exact", sample=sample, perm=perm, eps=eps, members=members)
         else:
             nobs, rew, done = self.engine.step(obs, actions, mode="fast", sample=sample, seed=self.seed, stream_id=self._steps,
                                                member_schedule=self._fixed_schedule)
@@ -268,6 +304,8 @@ class UnfusedTrajectoryEvalFn:
 
     def check_batch(self, pop: int):
         B, M = pop * self.num_particles, len(self.spec.members)
+        if self.spec.ensemble_kind == "basic_ensemble":  # BasicEnsemble.forward has no such rule (basic_ensemble.py:142-196)
+            return
         if B % M != 0:
             raise ValueError(
                 f"GaussianMLP ensemble requires batch size to be a multiple of the "

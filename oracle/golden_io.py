@@ -24,6 +24,7 @@ def save_case(path: str, om: OracleModel, meta: dict, arrays: dict):
         d["norm_mean"] = om.norm_mean.numpy()
         d["norm_std"] = om.norm_std.numpy()
     m = {k: getattr(om, k) for k in _SCALARS}
+    m["ensemble_kind"] = om.ensemble_kind
     m["elite_models"] = None if m["elite_models"] is None else [int(x) for x in m["elite_models"]]
     m["no_delta_list"] = [int(x) for x in m["no_delta_list"]]
     m["n_layers"] = len(om.weights)
@@ -45,6 +46,7 @@ def load_case(path: str):
         max_logvar=torch.from_numpy(z["max_logvar"]) if "max_logvar" in z else None,
         norm_mean=torch.from_numpy(z["norm_mean"]) if "norm_mean" in z else None,
         norm_std=torch.from_numpy(z["norm_std"]) if "norm_std" in z else None,
+        ensemble_kind=meta.get("ensemble_kind", "gaussian_mlp"),
         **{k: meta[k] for k in _SCALARS},
     )
     arrays = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x_")}

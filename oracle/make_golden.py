@@ -37,6 +37,14 @@ ROLLOUT_CASES = {
                                                target_is_delta=False), 16, 4, 7),
     "ts1_hopper_tanh": (11, 3, dict(ensemble_size=5, hid=24, num_layers=2, seed=15, activation="tanh", termination="hopper",
                                     reward="halfcheetah"), 25, 4, 8),
+    # BasicEnsemble of single-member GaussianMLPs (conf/dynamics_model/basic_ensemble.yaml): iid randint member maps,
+    # batch sizes that are NOT multiples of the ensemble size
+    "basic_tsinf_hopper": (11, 3, dict(ensemble_size=5, hid=32, seed=16, ensemble_kind="basic_ensemble", propagation="fixed_model",
+                                       termination="hopper"), 13, 3, 10),
+    "basic_ts1_halfcheetah": (17, 6, dict(ensemble_size=3, hid=40, seed=17, ensemble_kind="basic_ensemble", no_delta_list=[0]),
+                              11, 4, 5),
+    "basic_expectation": (8, 2, dict(ensemble_size=3, hid=24, seed=18, ensemble_kind="basic_ensemble", propagation="expectation",
+                                     normalizer="f32"), 7, 2, 4),
 }
 
 
@@ -61,21 +69,33 @@ def gen_rollout(name, obs, act, mkw, pop, P, H):
     gen2 = torch.Generator().manual_seed(7)
     arrays = dict(actions=actions, s0=s0, returns=ref)
     out = om.out_size
-    perms = None
+    perms = members = None
+    basic = om.ensemble_kind == "basic_ensemble"
+    M = len(om.active_members)
     if om.propagation == "fixed_model":
-        perms = torch.randperm(B)  # reset: sample_propagation_indices ignores the generator (gaussian_mlp.py:375)
-    plist, elist = [], []
+        if basic:  # reset: randint from ModelEnv's generator (basic_ensemble.py:255-260)
+            members = torch.randint(M, (B,), generator=gen2)
+        else:
+            perms = torch.randperm(B)  # reset: sample_propagation_indices ignores the generator (gaussian_mlp.py:375)
+    plist, mlist, elist = [], [], []
     for _ in range(H):
         if om.propagation == "random_model":
-            plist.append(torch.randperm(B))
+            if basic:  # basic_ensemble.py:122-129: generator draw, before this step's normal
+                mlist.append(torch.randint(M, (B,), generator=gen2))
+            else:
+                plist.append(torch.randperm(B))
         if not om.deterministic:
             elist.append(torch.empty(B, out).normal_(0, 1, generator=gen2))
     if plist:
         perms = torch.stack(plist)
+    if mlist:
+        members = torch.stack(mlist)
     eps = torch.stack(elist) if elist else None
     trace = {}
-    mine = po.rollout(om, actions, s0, P, perms=perms, eps=eps, trace=trace)
+    mine = po.rollout(om, actions, s0, P, perms=perms, eps=eps, members=members, trace=trace)
     assert torch.equal(ref, mine), f"{name}: oracle != reference (max diff {(ref - mine).abs().max()})"
+    if members is not None:
+        arrays["members"] = members
     if perms is not None:
         arrays["perms"] = perms
     if eps is not None:

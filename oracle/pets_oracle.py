@@ -55,6 +55,11 @@ class OracleModel:
     obs_process: str = "none"  # "none" | "halfcheetah" | "cartpole_pets"
     reward: Optional[str] = "halfcheetah"  # name in REWARD_FNS, or None => learned reward
     termination: str = "no_termination"
+    # "gaussian_mlp": one GaussianMLP with E members, balanced shuffles (gaussian_mlp.py:179-216).
+    # "basic_ensemble": BasicEnsemble of E single-member GaussianMLPs (conf/dynamics_model/basic_ensemble.yaml):
+    #   every row draws its member independently with randint FROM THE GENERATOR (basic_ensemble.py:122-129,
+    #   255-260), no batch-size check, elites ignored (:262-266).
+    ensemble_kind: str = "gaussian_mlp"
 
     @property
     def out_size(self) -> int:
@@ -64,6 +69,8 @@ class OracleModel:
     @property
     def active_members(self) -> List[int]:
         e = self.weights[0].shape[0]
+        if self.ensemble_kind == "basic_ensemble":
+            return list(range(e))
         return list(self.elite_models) if self.elite_models is not None else list(range(e))
 
 
@@ -217,6 +224,16 @@ def _members_forward(m: OracleModel, x: torch.Tensor):
     return mean, logvar
 
 
+def _single_member(m: OracleModel, slot: int) -> OracleModel:
+    """Active member ``slot`` as a one-member GaussianMLP.  A BasicEnsemble member is its own GaussianMLP with its own
+    learned logvar bounds (gaussian_mlp.py:117-122): ``min_logvar`` / ``max_logvar`` may then be [E, out]."""
+    member = m.active_members[slot]
+    kw = {"elite_models": [member], "ensemble_kind": "gaussian_mlp"}
+    if m.min_logvar is not None and m.min_logvar.shape[0] > 1:
+        kw["min_logvar"], kw["max_logvar"] = m.min_logvar[member:member + 1], m.max_logvar[member:member + 1]
+    return OracleModel(**{**m.__dict__, **kw})
+
+
 def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tensor] = None,
                      member_of_row: Optional[torch.Tensor] = None):
     """Propagation-aware forward (gaussian_mlp.py:179-216, 156-177).
@@ -229,7 +246,7 @@ def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tenso
     """
     B = x.shape[0]
     M = len(m.active_members)
-    if member_of_row is None and B % M != 0:  # gaussian_mlp.py:195-200 (checked for EVERY propagation method)
+    if member_of_row is None and m.ensemble_kind == "gaussian_mlp" and B % M != 0:  # gaussian_mlp.py:195-200 (EVERY method)
         raise ValueError(
             f"GaussianMLP ensemble requires batch size to be a multiple of the "
             f"number of models. Current batch size is {B} for "
@@ -243,8 +260,7 @@ def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tenso
                 rows = (member_of_row == s).nonzero().flatten()
                 if rows.numel() == 0:
                     continue
-                sub = OracleModel(**{**m.__dict__, "elite_models": [m.active_members[s]]})
-                mu_s, lv_s = _members_forward(sub, x[rows].unsqueeze(0))
+                mu_s, lv_s = _members_forward(_single_member(m, s), x[rows].unsqueeze(0))
                 mean[rows] = mu_s[0]
                 if lv_s is not None:
                     logvar[rows] = lv_s[0]
@@ -256,6 +272,12 @@ def ensemble_forward(m: OracleModel, x: torch.Tensor, perm: Optional[torch.Tenso
         if logvar is not None:
             logvar = logvar.reshape(B, -1)
             logvar[perm] = logvar.clone()  # :174
+        return mean, logvar
+    if m.propagation == "expectation" and m.ensemble_kind == "basic_ensemble":
+        # basic_ensemble.py:100-108, 131-137: one forward per member, stacked, then averaged (logvars too)
+        outs = [_members_forward(_single_member(m, s), x.unsqueeze(0)) for s in range(len(m.active_members))]
+        mean = torch.stack([o[0][0] for o in outs], dim=0).mean(dim=0)
+        logvar = None if outs[0][1] is None else torch.stack([o[1][0] for o in outs], dim=0).mean(dim=0)
         return mean, logvar
     if m.propagation == "expectation":  # :213-215 (averages log-variances, Appendix B12)
         mean, logvar = _members_forward(m, x.unsqueeze(0))
@@ -327,6 +349,10 @@ def rollout(
     term = torch.zeros(B, 1, dtype=torch.bool, device=dev)
     out = m.weights[-1].shape[-1] // (1 if m.deterministic else 2)
     fixed_perm = None
+    if m.ensemble_kind == "basic_ensemble" and members is None and m.propagation == "fixed_model":
+        # model.py:404-407 -> basic_ensemble.py:255-260: randint from ModelEnv's generator at reset
+        members = torch.randint(len(m.active_members), (B,), generator=generator, device=dev)
+    draw_members = m.ensemble_kind == "basic_ensemble" and members is None and m.propagation == "random_model"
     if m.propagation == "fixed_model" and members is None:
         # model.py:404-407 -> gaussian_mlp.py:363-375: randperm from the GLOBAL rng (the generator is
         # deliberately ignored there, see the comment at gaussian_mlp.py:374)
@@ -344,6 +370,8 @@ def rollout(
         mem = None
         if members is not None:
             mem = members[t] if members.ndim == 2 else members
+        elif draw_members:  # basic_ensemble.py:122-129: one randint per step, BEFORE that step's normal draw
+            mem = torch.randint(len(m.active_members), (B,), generator=generator, device=dev)
         elif m.propagation == "random_model":
             if perms is not None:
                 perm = perms[t]

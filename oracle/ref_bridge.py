@@ -66,22 +66,37 @@ def build_reference_model_env(om, obs_dim: int, act_dim: int, generator=None):
     hid = om.weights[0].shape[2]
     out_total = om.weights[-1].shape[2]
     out_size = out_total if om.deterministic else out_total // 2
-    model = mbrl.models.GaussianMLP(
-        in_size, out_size, "cpu", num_layers=len(om.weights) - 1, ensemble_size=E, hid_size=hid,
-        deterministic=om.deterministic, propagation_method=om.propagation,
-        activation_fn_cfg={"_target_": _ACT_TARGET[om.activation]},
-    )
-    with torch.no_grad():
-        for li in range(len(om.weights) - 1):
-            model.hidden_layers[li][0].weight.copy_(om.weights[li])
-            model.hidden_layers[li][0].bias.copy_(om.biases[li])
-        model.mean_and_logvar.weight.copy_(om.weights[-1])
-        model.mean_and_logvar.bias.copy_(om.biases[-1])
-        if not om.deterministic:
-            model.min_logvar.copy_(om.min_logvar)
-            model.max_logvar.copy_(om.max_logvar)
-    if om.elite_models is not None:
-        model.set_elite(list(om.elite_models))
+    def fill(gmlp, members):
+        with torch.no_grad():
+            for li in range(len(om.weights) - 1):
+                gmlp.hidden_layers[li][0].weight.copy_(om.weights[li][members])
+                gmlp.hidden_layers[li][0].bias.copy_(om.biases[li][members])
+            gmlp.mean_and_logvar.weight.copy_(om.weights[-1][members])
+            gmlp.mean_and_logvar.bias.copy_(om.biases[-1][members])
+            if not om.deterministic:
+                per_member = om.min_logvar.shape[0] > 1  # BasicEnsemble: each member owns its bounds
+                gmlp.min_logvar.copy_(om.min_logvar[members] if per_member else om.min_logvar)
+                gmlp.max_logvar.copy_(om.max_logvar[members] if per_member else om.max_logvar)
+
+    if getattr(om, "ensemble_kind", "gaussian_mlp") == "basic_ensemble":
+        # conf/dynamics_model/basic_ensemble.yaml: E single-member GaussianMLPs built by hydra.utils.instantiate
+        member_cfg = {
+            "_target_": "mbrl.models.GaussianMLP", "device": "cpu", "num_layers": len(om.weights) - 1, "in_size": in_size,
+            "out_size": out_size, "hid_size": hid, "deterministic": om.deterministic,
+            "activation_fn_cfg": {"_target_": _ACT_TARGET[om.activation]},
+        }
+        model = mbrl.models.BasicEnsemble(E, "cpu", member_cfg, propagation_method=om.propagation)
+        for i, member in enumerate(model.members):
+            fill(member, [i])
+    else:
+        model = mbrl.models.GaussianMLP(
+            in_size, out_size, "cpu", num_layers=len(om.weights) - 1, ensemble_size=E, hid_size=hid,
+            deterministic=om.deterministic, propagation_method=om.propagation,
+            activation_fn_cfg={"_target_": _ACT_TARGET[om.activation]},
+        )
+        fill(model, list(range(E)))
+        if om.elite_models is not None:
+            model.set_elite(list(om.elite_models))
     obs_fn = None
     if om.obs_process == "halfcheetah":
         from mbrl.env.pets_halfcheetah import HalfCheetahEnv

@@ -24,7 +24,7 @@ def to_spec(om, obs_dim, act_dim):
         max_logvar=om.max_logvar, elite_models=om.elite_models, activation=om.activation, propagation=om.propagation,
         deterministic=om.deterministic, norm_mean=om.norm_mean, norm_std=om.norm_std, target_is_delta=om.target_is_delta,
         no_delta_list=om.no_delta_list, learned_rewards=om.learned_rewards, obs_process=om.obs_process, reward=om.reward,
-        termination=om.termination,
+        termination=om.termination, ensemble_kind=om.ensemble_kind,
     )
 
 

@@ -36,7 +36,10 @@ def test_golden_reference_vectors_exact_mode(engine, path, R):
     trw = torch.zeros(H, B, device=DEV)
     perms = a["perms"].to(DEV) if "perms" in a else None
     eps = a["eps"].to(DEV) if "eps" in a else None
-    out = engine.rollout(a["actions"].to(DEV), a["s0"].numpy(), meta["P"], mode="exact", perms=perms, eps=eps,
+    members = a.get("members")  # BasicEnsemble cases: the reference's randint member maps (CPU or device, both accepted)
+    if members is not None and R == 1:
+        members = members.to(DEV)
+    out = engine.rollout(a["actions"].to(DEV), a["s0"].numpy(), meta["P"], mode="exact", perms=perms, eps=eps, members=members,
                          trace_next_obs=tno, trace_rewards=trw, rows_per_group=R)
     assert torch.allclose(tno[0].cpu(), a["next_obs_step0"], rtol=1e-5, atol=2e-6)  # T1
     assert torch.allclose(trw[0].cpu(), a["rewards_step0"].flatten(), rtol=1e-5, atol=2e-6)
@@ -272,3 +275,41 @@ def test_model_env_class_reset_step_fast_mode_replayed(engine):
         env.reset(obs0[:7])
     vals = env.evaluate_action_sequences(torch.zeros(10, 4, act, device=DEV), obs0[0], 5)
     assert vals.shape == (10,)
+
+
+def test_basic_ensemble_per_member_logvar_bounds_and_fast_mode(engine):
+    """BasicEnsemble of single-member GaussianMLPs: every member clamps with ITS OWN learned logvar bounds
+    (each member is its own GaussianMLP, gaussian_mlp.py:117-122); members are drawn iid.  EXACT vs the oracle with an
+    injected unbalanced map; FAST replayed through the oracle with the exported (iid, unbalanced) schedule."""
+    obs, act, pop, P, H, E = 9, 3, 37, 3, 6, 4
+    om = po.make_synthetic_model(obs, act, ensemble_size=E, hid=32, seed=21, ensemble_kind="basic_ensemble")
+    g = torch.Generator().manual_seed(5)
+    lo = -10 + torch.rand(E, obs, generator=g) * 6      # per-member bounds, far enough apart to matter
+    hi = -3 + torch.rand(E, obs, generator=g) * 3
+    om.min_logvar, om.max_logvar = lo, hi
+    engine.set_model(to_spec(om, obs, act))
+    B = pop * P
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+    members = torch.randint(E, (H, B), generator=g)
+    members[:, : B // 2] = 0  # strongly unbalanced on purpose
+    eps = torch.randn(H, B, obs, generator=g)
+
+    def oracle(member_map, eps_):
+        return po.rollout(om, actions, s0, P, members=member_map, eps=eps_)
+
+    ref = oracle(members, eps)
+    out = engine.rollout(actions.to(DEV), s0, P, mode="exact", members=members, eps=eps.to(DEV))
+    assert_returns_close(out, ref)
+    # FAST: iid schedule (not balanced), replay
+    seed, sid = 3, 8
+    nwg, r = engine.fast_geometry(pop, P, H)
+    out_f = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
+    sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
+    assert sched.min() >= 0 and sched.max() < E
+    rows = torch.arange(B)
+    wg = ((rows // P) // (16 * r)) * P + rows % P
+    fast_members = torch.stack([sched[t][wg].long() for t in range(H)])
+    assert_returns_close(out_f, oracle(fast_members, engine.fast_normals(H, B, seed, sid).cpu()))
+    # batch sizes that are not multiples of the ensemble size are accepted (no GaussianMLP batch rule)
+    assert B % E != 0

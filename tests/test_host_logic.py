@@ -155,3 +155,26 @@ def test_spec_from_checkpoint_files(tmp_path):
     assert spec.members == [2, 0] and spec.termination == "hopper" and not spec.deterministic
     assert spec.norm_mean.dtype == torch.float64 and float(spec.norm_std[0, 0]) == 2.0
     assert len(spec.weights) == 3 and torch.equal(spec.weights[1], s.weights[1] + 1)
+
+
+def test_member_slots_pads_unbalanced_member_maps():
+    """Row -> member maps of BasicEnsemble models (randint, unbalanced) become padded per-member slot tables."""
+    from hipets.engine import member_slots
+
+    g = torch.Generator().manual_seed(0)
+    T, B, M = 3, 29, 4
+    members = torch.randint(M, (T, B), generator=g)
+    members[1] = 2  # one step where a single member owns every row
+    slots, rpm = member_slots(members, M, "cpu")
+    assert rpm == B and tuple(slots.shape) == (T, M * rpm)
+    for t in range(T):
+        seen = []
+        for m in range(M):
+            blk = slots[t, m * rpm:(m + 1) * rpm]
+            rows = blk[blk >= 0]
+            assert torch.equal(rows, (members[t] == m).nonzero().flatten())  # ascending rows of member m ...
+            assert (blk[len(rows):] == -1).all()  # ... then padding only
+            seen.append(rows)
+        assert torch.equal(torch.cat(seen).sort().values, torch.arange(B))
+    tight, rpm2 = member_slots(members[:1], M, "cpu")
+    assert rpm2 == int(torch.bincount(members[0], minlength=M).max()) and tight.shape[1] == M * rpm2

@@ -17,14 +17,15 @@ CEM_FILES = sorted(glob.glob(os.path.join(GOLDEN, "cem_*.npz")))
 
 
 def test_golden_present():
-    assert len(ROLLOUT_FILES) >= 6 and len(CEM_FILES) >= 3
+    assert len(ROLLOUT_FILES) >= 9 and len(CEM_FILES) >= 3
 
 
 @pytest.mark.parametrize("path", ROLLOUT_FILES, ids=lambda p: os.path.basename(p)[8:-4])
 def test_rollout_matches_reference_golden(path):
     om, meta, a = load_case(path)
     trace = {}
-    out = po.rollout(om, a["actions"], a["s0"].numpy(), meta["P"], perms=a.get("perms"), eps=a.get("eps"), trace=trace)
+    out = po.rollout(om, a["actions"], a["s0"].numpy(), meta["P"], perms=a.get("perms"), eps=a.get("eps"),
+                     members=a.get("members"), trace=trace)
     assert torch.equal(out, a["returns"])  # T0: bitwise
     assert torch.equal(trace["next_obs"][0], a["next_obs_step0"])
     assert torch.equal(trace["rewards"][0], a["rewards_step0"])

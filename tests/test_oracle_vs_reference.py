@@ -26,10 +26,16 @@ CASES = [
     dict(obs=5, act=2, mkw=dict(ensemble_size=2, hid=16, seed=4, termination="inverted_pendulum", reward="inverted_pendulum",
                                 normalizer="none"), pop=8, P=3, H=6),
     dict(obs=20, act=7, mkw=dict(ensemble_size=2, hid=16, seed=5, reward="pusher", activation="leaky_relu"), pop=4, P=2, H=3),
+    # BasicEnsemble of single-member GaussianMLPs: randint member maps from the generator, any batch size
+    dict(obs=9, act=3, mkw=dict(ensemble_size=5, hid=32, seed=6, ensemble_kind="basic_ensemble", propagation="fixed_model"),
+         pop=13, P=3, H=10),
+    dict(obs=17, act=6, mkw=dict(ensemble_size=3, hid=24, seed=7, ensemble_kind="basic_ensemble"), pop=11, P=4, H=5),
+    dict(obs=8, act=2, mkw=dict(ensemble_size=3, hid=16, seed=8, ensemble_kind="basic_ensemble", propagation="expectation"),
+         pop=7, P=2, H=4),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"obs{c['obs']}_{c['mkw'].get('propagation', 'random_model')}")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"obs{c['obs']}_{c['mkw'].get('ensemble_kind', 'gmlp')}_{c['mkw'].get('propagation', 'random_model')}")
 def test_rollout_bitwise_vs_reference(mbrl, case):
     om = po.make_synthetic_model(case["obs"], case["act"], **case["mkw"])
     g = torch.Generator().manual_seed(9)
@@ -44,6 +50,22 @@ def test_rollout_bitwise_vs_reference(mbrl, case):
     ref = me.evaluate_action_sequences(actions, s0, case["P"])
     torch.manual_seed(42)
     mine = po.rollout(om, actions, s0, case["P"], global_rng=True, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(ref, mine)
+
+
+@pytest.mark.parametrize("propagation", ["random_model", "fixed_model", "expectation"])
+def test_basic_ensemble_per_member_logvar_bounds_bitwise(mbrl, propagation):
+    """Every BasicEnsemble member is its own GaussianMLP with its own (learned) logvar bounds."""
+    obs, act, E, pop, P, H = 7, 2, 4, 9, 3, 5
+    om = po.make_synthetic_model(obs, act, ensemble_size=E, hid=16, seed=31, ensemble_kind="basic_ensemble", propagation=propagation)
+    g = torch.Generator().manual_seed(2)
+    om.min_logvar = -10 + torch.rand(E, obs, generator=g) * 6
+    om.max_logvar = -3 + torch.rand(E, obs, generator=g) * 3
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = (np.random.default_rng(4).standard_normal(obs) * 0.1).astype(np.float32)
+    me, _, _ = build_reference_model_env(om, obs, act, generator=torch.Generator().manual_seed(1))
+    ref = me.evaluate_action_sequences(actions, s0, P)
+    mine = po.rollout(om, actions, s0, P, generator=torch.Generator().manual_seed(1))
     assert torch.equal(ref, mine)
 
 
@@ -197,6 +219,27 @@ def test_spec_extraction_from_live_reference_objects(mbrl):
     assert hipets.model_version(me) != v0
     model.set_elite([0, 1, 2, 3, 4])
     assert hipets.spec_from_model_env(me).members == [0, 1, 2, 3, 4]
+
+
+def test_spec_extraction_from_live_basic_ensemble(mbrl):
+    """The second model config of the reference's tests (conf/dynamics_model/basic_ensemble.yaml,
+    tests/algorithms/test_algorithms.py:197-198): BasicEnsemble of single-member GaussianMLPs -> one stacked spec."""
+    import hipets
+
+    om = po.make_synthetic_model(8, 2, ensemble_size=4, hid=16, seed=3, ensemble_kind="basic_ensemble", propagation="fixed_model")
+    g = torch.Generator().manual_seed(0)
+    om.min_logvar, om.max_logvar = -10 + torch.rand(4, 8, generator=g), torch.rand(4, 8, generator=g)
+    me, dm, model = build_reference_model_env(om, 8, 2, generator=torch.Generator())
+    assert type(model).__name__ == "BasicEnsemble"
+    spec = hipets.spec_from_model_env(me)
+    assert spec.ensemble_kind == "basic_ensemble" and spec.members == [0, 1, 2, 3] and spec.propagation == "fixed_model"
+    for a, b in zip(spec.weights, om.weights):
+        assert torch.equal(a, b)
+    assert torch.equal(spec.min_logvar, om.min_logvar) and torch.equal(spec.max_logvar, om.max_logvar)
+    v0 = hipets.model_version(me)
+    with torch.no_grad():
+        model.members[2].mean_and_logvar.weight.add_(1.0)
+    assert hipets.model_version(me) != v0
 
 
 def test_spec_from_checkpoint_written_by_the_reference(mbrl, tmp_path):
