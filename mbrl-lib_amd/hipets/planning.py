@@ -325,9 +325,14 @@ class UnfusedTrajectoryEvalFn:
         obs = torch.as_tensor(np.asarray(initial_state, np.float32), device=self.device).repeat(pop * P, 1).contiguous()
         total = torch.zeros(pop * P, 1, device=self.device)
         terminated = torch.zeros(pop * P, 1, dtype=torch.bool, device=self.device)
+        schedule = None
+        if self.spec.propagation == "fixed_model":  # TS-infinity: one member map for the whole horizon (model.py:404-407)
+            nwg, _ = self.engine.fast_geometry(pop * P, 1, 1)
+            schedule = self.engine.fast_schedule(1, nwg, self.seed, self.calls * 4096).contiguous()
         for t in range(H):
             act = torch.repeat_interleave(a_seq[:, t, :], P, dim=0).contiguous()  # model_env.py:179-182
-            nobs, rew, done = self.engine.step(obs, act, mode="fast", sample=True, seed=self.seed, stream_id=self.calls * 4096 + t)
+            nobs, rew, done = self.engine.step(obs, act, mode="fast", sample=True, seed=self.seed, stream_id=self.calls * 4096 + t,
+                                               member_schedule=schedule)
             if self.reward_fn is not None:
                 rew = self.reward_fn(act, nobs)
             if self.termination_fn is not None:

@@ -73,7 +73,7 @@ def collect_random(env, n, rng):
     return f(o), f(a), f(nx)
 
 
-@pytest.mark.parametrize("objective", ["unfused_python_reward", "fused_enum_reward"])
+@pytest.mark.parametrize("objective", ["unfused_python_reward", "unfused_basic_ensemble_tsinf", "fused_enum_reward"])
 def test_pets_solves_the_point_mass_task(engine, objective):
     torch.manual_seed(12345)
     rng = np.random.default_rng(12345)
@@ -82,7 +82,13 @@ def test_pets_solves_the_point_mass_task(engine, objective):
     ws, bs, mn, mx, nmean, nstd = train_ensemble(o, a, nx)
     kw = dict(weights=ws, biases=bs, obs_dim=2, act_dim=1, min_logvar=mn, max_logvar=mx, norm_mean=nmean, norm_std=nstd,
               activation="silu", propagation="random_model")
-    if objective == "unfused_python_reward":
+    if objective == "unfused_basic_ensemble_tsinf":
+        # the reference's second model config (tests/algorithms/test_algorithms.py:197-198, conf/dynamics_model/
+        # basic_ensemble.yaml): BasicEnsemble semantics (iid member draws, any batch size) with TS-infinity propagation
+        kw.update(ensemble_kind="basic_ensemble", propagation="fixed_model")
+        spec = hipets.ModelSpec(reward="none", termination="no_termination", **kw)
+        fn = hipets.UnfusedTrajectoryEvalFn(spec, 7, reward_fn=mock_reward_fn, engine=engine, seed=1)  # 500 * 7 % 5 == 0 not needed
+    elif objective == "unfused_python_reward":
         spec = hipets.ModelSpec(reward="none", termination="no_termination", **kw)
         fn = hipets.UnfusedTrajectoryEvalFn(spec, 20, reward_fn=mock_reward_fn, engine=engine, seed=1)
     else:

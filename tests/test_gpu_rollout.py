@@ -313,3 +313,31 @@ def test_basic_ensemble_per_member_logvar_bounds_and_fast_mode(engine):
     assert_returns_close(out_f, oracle(fast_members, engine.fast_normals(H, B, seed, sid).cpu()))
     # batch sizes that are not multiples of the ensemble size are accepted (no GaussianMLP batch rule)
     assert B % E != 0
+
+
+@pytest.mark.parametrize("propagation", ["random_model", "fixed_model"])
+def test_model_env_exact_mode_basic_ensemble_replays_generator_order(engine, propagation):
+    """hipets.ModelEnv in EXACT mode on a BasicEnsemble model draws what the reference draws, from the same generator in
+    the same order (reset: fixed_model randint; step: random_model randint, then the normal): two steps replayed through
+    the oracle with the draws regenerated from an identically seeded generator."""
+    import hipets
+
+    obs, act, B, E = 7, 2, 23, 4  # 23 rows: not a multiple of the ensemble size, accepted for BasicEnsemble
+    om = po.make_synthetic_model(obs, act, ensemble_size=E, hid=24, seed=4, ensemble_kind="basic_ensemble", propagation=propagation)
+    env = hipets.ModelEnv(to_spec(om, obs, act), engine=engine, mode="exact", seed=0)
+    env._eval._rng = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(1)
+    obs0 = (torch.randn(B, obs, generator=g) * 0.2).numpy().astype(np.float32)
+    acts = [torch.rand(B, act, generator=g) * 2 - 1 for _ in range(2)]
+    state = env.reset(obs0, return_as_np=False)
+    replay = torch.Generator().manual_seed(77)
+    fixed = torch.randint(E, (B,), generator=replay) if propagation == "fixed_model" else None
+    x = torch.from_numpy(obs0)
+    for a in acts:
+        nobs, rew, done, state = env.step(a.to(DEV), state, sample=True)
+        members = fixed if fixed is not None else torch.randint(E, (B,), generator=replay)
+        eps = torch.empty(B, obs).normal_(0.0, 1.0, generator=replay)
+        rn, rr, rd = po.step(om, x, a, member_of_row=members, eps=eps, sample=True)
+        assert torch.allclose(nobs.cpu(), rn, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), rr, rtol=1e-5, atol=2e-6)
+        assert torch.equal(done.cpu(), rd)
+        x = rn
