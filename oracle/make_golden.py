@@ -9,6 +9,7 @@ While generating, the script also asserts oracle == reference bitwise for every 
 """
 from __future__ import annotations
 
+import json
 import os
 import sys
 
@@ -240,6 +241,33 @@ def gen_icem(pop=60, H=8, A=3, iters=4, ratio=0.1, decay=1.3, exponent=2.0, keep
     print(f"icem_two_calls: oracle==reference bitwise; evaluated population sizes {sizes}")
 
 
+def gen_planet(name, latent, action, belief, hidden, pop, P, H, seed):
+    """PlaNet latent rollouts through the unmodified reference (ModelEnv + PlaNetModel), draws recorded by replaying the
+    generator (one randn [B, latent] per step, planet.py:299-305)."""
+    from oracle import planet_oracle as pl
+    from oracle.ref_bridge import build_reference_planet_env
+
+    pm = pl.make_synthetic_planet(latent, action, belief, hidden, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    latent0, belief0 = torch.randn(1, latent, generator=g) * 0.3, torch.randn(1, belief, generator=g) * 0.3
+    actions = torch.rand(pop, H, action, generator=g) * 2 - 1
+    me, _ = build_reference_planet_env(pm, latent0, belief0, generator=torch.Generator().manual_seed(11))
+    ref = me.evaluate_action_sequences(actions, np.zeros((3, 16, 16), np.float32), P)
+    gen2 = torch.Generator().manual_seed(11)
+    eps = torch.stack([torch.randn(pop * P, latent, generator=gen2) for _ in range(H)])
+    trace = {}
+    mine = pl.planet_rollout(pm, actions, latent0, belief0, P, eps=eps, trace=trace)
+    assert torch.equal(ref, mine), f"{name}: oracle != reference"
+    d = {k: getattr(pm, k).numpy() for k in pl.PLANET_TENSORS}
+    d.update(x_actions=actions.numpy(), x_latent0=latent0.numpy(), x_belief0=belief0.numpy(), x_eps=eps.numpy(), x_returns=ref.numpy(),
+             x_latent_step0=trace["latent"][0].numpy(), x_belief_step0=trace["belief"][0].numpy(),
+             x_rewards_step0=trace["rewards"][0].numpy())
+    meta = dict(kind="planet", pop=pop, P=P, H=H, min_std=pm.min_std)
+    d["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez(os.path.join(OUT, f"planet_{name}.npz"), **d)
+    print(f"planet_{name}: B={pop * P} returns[{ref.min():.3f},{ref.max():.3f}]  oracle==reference bitwise")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -250,6 +278,8 @@ def main():
     gen_cem("clipped_mean", clipped=True, return_mean=True)
     gen_mppi()
     gen_icem()
+    gen_planet("cheetah_shape", 30, 6, 200, 200, pop=40, P=1, H=12, seed=1)   # conf/dynamics_model/planet.yaml sizes
+    gen_planet("small_particles", 10, 3, 40, 24, pop=11, P=3, H=5, seed=2)
 
 
 if __name__ == "__main__":

@@ -120,3 +120,41 @@ def build_reference_model_env(om, obs_dim: int, act_dim: int, generator=None):
     env = _FakeEnv(obs_dim, act_dim)
     me = mbrl.models.ModelEnv(env, dm, term_fn, reward_fn, generator=generator)
     return me, dm, model
+
+
+def build_reference_planet_env(pm, latent0, belief0, generator=None, obs_hw: int = 16):
+    """PlaNetOracleModel -> (mbrl.models.ModelEnv, PlaNetModel) of the unmodified reference, with the planning heads
+    overwritten by ``pm``'s tensors and the saved posterior / belief set as update_posterior would leave them
+    (planet.py:600-640).  The conv encoder / decoder are irrelevant to planning and kept tiny."""
+    mbrl = import_reference()
+    from mbrl.env import termination_fns
+
+    model = mbrl.models.PlaNetModel(
+        obs_shape=(3, obs_hw, obs_hw), obs_encoding_size=32, encoder_config=((3, 4, 4, 2),),
+        decoder_config=((8, 1, 1), ((8, 3, obs_hw, 1),)), latent_state_size=pm.latent_size, action_size=pm.action_size,
+        belief_size=pm.belief_size, hidden_size_fcs=pm.hidden_size, device="cpu", min_std=pm.min_std,
+    )
+    with torch.no_grad():
+        model.belief_model.embedding_layer[0].weight.copy_(pm.w_embed)
+        model.belief_model.embedding_layer[0].bias.copy_(pm.b_embed)
+        model.belief_model.rnn.weight_ih.copy_(pm.w_ih)
+        model.belief_model.rnn.bias_ih.copy_(pm.b_ih)
+        model.belief_model.rnn.weight_hh.copy_(pm.w_hh)
+        model.belief_model.rnn.bias_hh.copy_(pm.b_hh)
+        for seq, names in ((model.prior_transition_model, ("prior1", None, "prior2")),
+                           (model.reward_model, ("rew1", None, "rew2", None, "rew3"))):
+            for i, n in enumerate(names):
+                if n is not None:
+                    seq[i].weight.copy_(getattr(pm, "w_" + n))
+                    seq[i].bias.copy_(getattr(pm, "b_" + n))
+    model._current_posterior_sample = latent0.reshape(1, -1).clone()
+    model._current_belief = belief0.reshape(1, -1).clone()
+
+    class _Env:
+        import gymnasium as gym
+
+        observation_space = gym.spaces.Box(0, 255, shape=(3, obs_hw, obs_hw))
+        action_space = gym.spaces.Box(-1.0, 1.0, shape=(pm.action_size,))
+
+    me = mbrl.models.ModelEnv(_Env(), model, termination_fns.no_termination, generator=generator)  # algorithms/planet.py
+    return me, model

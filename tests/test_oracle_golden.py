@@ -190,3 +190,29 @@ def test_colored_noise_from_injected_normals_matches_recorded_noise():
     n = a["normals_0_0"]
     cn = po.powerlaw_psd_gaussian(meta["exponent"], size=(n.shape[1], meta["A"], meta["H"]), normals=(n[0], n[1])).transpose(1, 2)
     assert torch.equal(cn, a["noise_0_0"])
+
+
+def load_planet_case(path):
+    from oracle import planet_oracle as pl
+
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    pm = pl.PlaNetOracleModel(**{k: torch.from_numpy(z[k]) for k in pl.PLANET_TENSORS}, min_std=meta["min_std"])
+    arrays = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x_")}
+    return pm, meta, arrays
+
+
+PLANET_FILES = sorted(glob.glob(os.path.join(GOLDEN, "planet_*.npz")))
+
+
+@pytest.mark.parametrize("path", PLANET_FILES, ids=lambda p: os.path.basename(p)[7:-4])
+def test_planet_rollout_matches_reference_golden(path):
+    from oracle import planet_oracle as pl
+
+    pm, meta, a = load_planet_case(path)
+    trace = {}
+    out = pl.planet_rollout(pm, a["actions"], a["latent0"], a["belief0"], meta["P"], eps=a["eps"], trace=trace)
+    assert torch.equal(out, a["returns"])
+    assert torch.equal(trace["latent"][0], a["latent_step0"]) and torch.equal(trace["belief"][0], a["belief_step0"])
+    assert torch.equal(trace["rewards"][0], a["rewards_step0"])
+    assert len(PLANET_FILES) >= 2

@@ -282,3 +282,29 @@ def test_oracle_step_bitwise_vs_reference_model_env_step(mbrl, sample):
         outs.append((x, r, d))
     assert torch.equal(n1, outs[0][0]) and torch.equal(r1, outs[0][1]) and torch.equal(d1, outs[0][2])
     assert torch.equal(n2, outs[1][0]) and torch.equal(r2, outs[1][1]) and torch.equal(d2, outs[1][2])
+
+
+# ---- PlaNet latent planning path -------------------------------------------------------------
+@pytest.mark.parametrize("P", [1, 3])
+def test_planet_rollout_bitwise_vs_reference(mbrl, P):
+    from oracle import planet_oracle as pl
+    from oracle.ref_bridge import build_reference_planet_env
+
+    pm = pl.make_synthetic_planet(latent=10, action=3, belief=24, hidden=20, seed=2)
+    g = torch.Generator().manual_seed(0)
+    latent0, belief0 = torch.randn(1, 10, generator=g) * 0.3, torch.randn(1, 24, generator=g) * 0.3
+    pop, H = 9, 6
+    actions = torch.rand(pop, H, 3, generator=g) * 2 - 1
+    me, model = build_reference_planet_env(pm, latent0, belief0, generator=torch.Generator().manual_seed(5))
+    obs = np.zeros((3, 16, 16), np.float32)  # only its batch dimension is used (planet.py:669-672)
+    ref = me.evaluate_action_sequences(actions, obs, P)
+    mine = pl.planet_rollout(pm, actions, latent0, belief0, P, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(ref, mine)
+    # one step, against PlaNetModel.sample directly (deterministic and sampled)
+    B = 7
+    lat, bel, act = torch.randn(B, 10, generator=g), torch.randn(B, 24, generator=g), torch.rand(B, 3, generator=g)
+    for det in (True, False):
+        r_lat, r_rew, _, r_state = model.sample(act, {"latent": lat, "belief": bel}, deterministic=det,
+                                                rng=torch.Generator().manual_seed(8))
+        o_lat, o_rew, o_bel = pl.planet_step(pm, lat, bel, act, generator=torch.Generator().manual_seed(8), deterministic=det)
+        assert torch.equal(r_lat, o_lat) and torch.equal(r_rew, o_rew) and torch.equal(r_state["belief"], o_bel)
