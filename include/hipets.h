@@ -254,6 +254,50 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
                      float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t num_particles,
                      uint64_t seed, uint64_t plan_id, float* out, void* stream);
 
+/* ---- PlaNet latent planner (mbrl/models/planet.py) ----------------------------------- */
+/* The tensors PlaNetModel.sample reads (planet.py:531-581), DEVICE f32 in nn.Linear layout: weights [out, in]
+ * row-major, biases [out].  The library packs private copies; call again after every model update.            */
+typedef struct {
+    int32_t latent_size;     /* latent_state_size                                                               */
+    int32_t action_size;
+    int32_t belief_size;
+    int32_t hidden_size;     /* hidden_size_fcs                                                                 */
+    float min_std;           /* MeanStdCat (planet.py:104-115)                                                  */
+    const void* w_embed;     /* belief_model.embedding_layer[0]  [belief, latent + action]   (planet.py:86-88)  */
+    const void* b_embed;
+    const void* w_ih;        /* belief_model.rnn (GRUCell) weight_ih [3 belief, belief], gates r | z | n  (:89) */
+    const void* b_ih;
+    const void* w_hh;        /* weight_hh [3 belief, belief]                                                    */
+    const void* b_hh;
+    const void* w_prior1;    /* prior_transition_model[0] [hidden, belief]                        (:229-234)   */
+    const void* b_prior1;
+    const void* w_prior2;    /* prior_transition_model[2] [2 latent, hidden]                                    */
+    const void* b_prior2;
+    const void* w_rew1;      /* reward_model[0] [hidden, belief + latent]                          (:260-266)   */
+    const void* b_rew1;
+    const void* w_rew2;      /* reward_model[2] [hidden, hidden]                                                */
+    const void* b_rew2;
+    const void* w_rew3;      /* reward_model[4] [1, hidden]                                                     */
+    const void* b_rew3;
+} hipets_planet_desc;
+int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void* stream);
+
+typedef struct {
+    const float* eps;        /* DEVICE [H,B,latent] injected N(0,1) draws of planet.py:299-305; NULL => Philox   */
+    uint64_t seed;
+    uint64_t stream_id;
+    int32_t no_sample;       /* latent = prior mean (sample(deterministic=True))                                 */
+    float* trace_latent;     /* optional DEVICE taps: [H,B,latent], [H,B,belief], [H,B]                          */
+    float* trace_belief;
+    float* trace_rewards;
+} hipets_planet_opts;
+/* ModelEnv.evaluate_action_sequences on a PlaNetModel with no_termination and the learned reward head
+ * (model_env.py:145-191, mbrl/algorithms/planet.py): actions DEVICE [pop,H,A]; latent0 / belief0 DEVICE [latent] /
+ * [belief] = the model's saved posterior sample and belief (planet.py:669-672), tiled over the pop * P rows;
+ * returns DEVICE [pop] particle-averaged.  One kernel launch for the whole horizon.                              */
+int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop,
+                          int32_t horizon, int32_t num_particles, const hipets_planet_opts* opts, float* returns, void* stream);
+
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 /* When enabled, every rollout-kernel launch is bracketed by hipEvents on `stream`.              */
 int hipets_timing_enable(hipets_engine* e, int32_t on);

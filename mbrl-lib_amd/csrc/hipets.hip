@@ -12,6 +12,7 @@
 #include "../../include/hipets.h"
 #include "cem.hpp"
 #include "optim.hpp"
+#include "planet.hpp"
 #include "rollout.hpp"
 
 using namespace hipets;
@@ -74,6 +75,11 @@ struct hipets_engine {
     DevBuf s0, state, totals, term, schedule;
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
+    // PlaNet latent model
+    bool has_planet = false;
+    PlanetDev pd{};
+    DevBuf planet_w, planet_b, planet_member, planet_ops;
+    bool planet_lds_attr_set = false;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -220,7 +226,7 @@ void hipets_destroy(hipets_engine* e) {
     (void)hipSetDevice(e->device);
     for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
                       &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->mu, &e->disp, &e->population, &e->values,
-                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx})
+                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -303,7 +309,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         const long long n = (long long)lms[l].Kp * lms[l].Np * md.M;
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e->wpack.as<float>(),
                            reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp,
-                           lms[l].Np, md.wmember, lms[l].woff, l < d->n_layers - 1 ? 1 : 0);
+                           lms[l].Np, md.wmember, lms[l].woff, l < d->n_layers - 1 ? 1 : 0, 0);
         HCHECK(hipGetLastError());
         const int nb = md.M * lms[l].Np;
         hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
@@ -827,6 +833,121 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         has_elite = 1;
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void* stream) {
+    if (!e || !d) return fail("null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    if (d->latent_size < 1 || d->action_size < 1 || d->belief_size < 1 || d->hidden_size < 1) return fail("bad PlaNet dimensions");
+    const void* ptrs[] = {d->w_embed, d->b_embed, d->w_ih, d->b_ih, d->w_hh, d->b_hh, d->w_prior1, d->b_prior1,
+                          d->w_prior2, d->b_prior2, d->w_rew1, d->b_rew1, d->w_rew2, d->b_rew2, d->w_rew3, d->b_rew3};
+    for (const void* p : ptrs)
+        if (!p) return fail("null PlaNet tensor");
+    const int L = d->latent_size, A = d->action_size, Hb = d->belief_size, F = d->hidden_size;
+    auto up16 = [](int x) { return (x + 15) / 16 * 16; };
+    PlanetDev pd{};
+    pd.latent = L; pd.action = A; pd.belief = Hb; pd.hidden = F; pd.min_std = d->min_std;
+    pd.widA = up16(L + A);
+    pd.widE = up16(Hb + L);
+    const int widB = up16(std::max(Hb, F)), widC = up16(std::max(3 * Hb, F)), widD = up16(std::max(std::max(3 * Hb, 2 * L), 16));
+    pd.segA = 0; pd.segB = pd.widA; pd.segC = pd.segB + widB; pd.segD = pd.segC + widC; pd.segE = pd.segD + widD;
+    int ld = pd.segE + pd.widE;
+    while (ld % 64 != 8) ld += 4;  // conflict-free ds_read_b128 A fragments (see rollout.hpp)
+    pd.ld = ld;
+    if (planet_smem_bytes(ld) > e->lds_max) return fail("PlaNet model too wide for LDS (row of %d floats)", ld);
+    // op table: K, N, source tensors, whether the output feeds another GEMM (chunk-transposed columns)
+    struct OpSrc { int K, N; const void* w; const void* b; int permute; };
+    const OpSrc ops[kPlanetOps] = {
+        {L + A, Hb, d->w_embed, d->b_embed, 1},   {Hb, 3 * Hb, d->w_ih, d->b_ih, 0},     {Hb, 3 * Hb, d->w_hh, d->b_hh, 0},
+        {Hb, F, d->w_prior1, d->b_prior1, 1},     {F, 2 * L, d->w_prior2, d->b_prior2, 0}, {Hb + L, F, d->w_rew1, d->b_rew1, 1},
+        {F, F, d->w_rew2, d->b_rew2, 1},          {F, 1, d->w_rew3, d->b_rew3, 0}};
+    long long woff = 0;
+    int boff = 0;
+    // execution order: embed, hidden gates, input gates, prior x2, reward head x3 (ops[] above is in tensor order)
+    PlanetOp table[kPlanetOps];
+    const int order[kPlanetOps] = {PL_EMBED, PL_GH, PL_GI, PL_PRIOR1, PL_PRIOR2, PL_REW1, PL_REW2, PL_REW3};
+    const int in_off[kPlanetOps] = {pd.segA, pd.segE, pd.segB, pd.segE, pd.segB, pd.segE, pd.segB, pd.segC};
+    const int out_off[kPlanetOps] = {pd.segB, pd.segD, pd.segC, pd.segB, pd.segD, pd.segB, pd.segC, pd.segD};
+    const int relu[kPlanetOps] = {1, 0, 0, 1, 0, 1, 1, 0};
+    const int post[kPlanetOps] = {PL_POST_NONE, PL_POST_SYNC, PL_POST_GRU, PL_POST_SYNC, PL_POST_SAMPLE, PL_POST_SYNC, PL_POST_SYNC,
+                                  PL_POST_REWARD};
+    for (int x = 0; x < kPlanetOps; ++x) {
+        const int i = order[x];
+        table[x].in_off = in_off[x];
+        table[x].out_off = out_off[x];
+        table[x].relu = relu[x];
+        table[x].post = post[x];
+        LayerMeta& lm = table[x].lm;
+        lm.Kp = up16(ops[i].K);
+        lm.Np = up16(ops[i].N);
+        lm.woff = woff;
+        lm.boff = boff;
+        lm.tail_steps = (ops[i].K - (lm.Kp - 16) + 3) / 4;
+        woff += (long long)lm.Kp * lm.Np;
+        boff += lm.Np;
+    }
+    if (e->planet_w.ensure((size_t)woff * 4) || e->planet_b.ensure((size_t)boff * 4) || e->planet_member.ensure(16)) return 1;
+    int* zero_member = e->planet_member.as<int>();  // the pack kernels index "member 0" of a one-member set
+    HCHECK(hipMemsetAsync(zero_member, 0, 4, st));
+    if (e->planet_ops.ensure(sizeof(table))) return 1;
+    HCHECK(hipMemcpyAsync(e->planet_ops.p, table, sizeof(table), hipMemcpyHostToDevice, st));
+    for (int x = 0; x < kPlanetOps; ++x) {
+        const int i = order[x];
+        const LayerMeta& lm = table[x].lm;
+        const long long n = (long long)lm.Kp * lm.Np;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e->planet_w.as<float>(),
+                           reinterpret_cast<const float*>(ops[i].w), zero_member, 1, ops[i].K, ops[i].N, lm.Kp, lm.Np, woff, lm.woff,
+                           ops[i].permute, 1);
+        HCHECK(hipGetLastError());
+        hipLaunchKernelGGL(pack_bias_kernel, dim3((lm.Np + 255) / 256), dim3(256), 0, st, e->planet_b.as<float>(),
+                           reinterpret_cast<const float*>(ops[i].b), zero_member, 1, ops[i].N, lm.Np, boff, lm.boff, ops[i].permute);
+        HCHECK(hipGetLastError());
+    }
+    HCHECK(hipStreamSynchronize(st));  // the caller's tensors may go away after return
+    pd.w = e->planet_w.as<float>();
+    pd.b = e->planet_b.as<float>();
+    pd.ops = e->planet_ops.as<PlanetOp>();
+    e->pd = pd;
+    e->has_planet = true;
+    return 0;
+}
+
+int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop, int32_t H,
+                          int32_t P, const hipets_planet_opts* o, float* returns, void* stream) {
+    if (!e || !e->has_planet) return fail("engine has no PlaNet model (call hipets_planet_set_model)");
+    if (!actions || !latent0 || !belief0 || !o || !returns) return fail("null argument");
+    if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const long long B = (long long)pop * P;
+    if (B > 0x7FFFFFFF / std::max(e->pd.belief, 16)) return fail("batch too large");
+    if (e->totals.ensure((size_t)B * 4)) return 1;
+    PlanetArgs ra{};
+    ra.pop = pop; ra.P = P; ra.H = H; ra.B = (int)B;
+    ra.actions = actions;
+    ra.latent0 = latent0;
+    ra.belief0 = belief0;
+    ra.totals = e->totals.as<float>();
+    ra.eps = o->eps;
+    ra.use_philox = (o->eps || o->no_sample) ? 0 : 1;
+    ra.seed = o->seed;
+    ra.stream_id = o->stream_id;
+    ra.trace_latent = o->trace_latent;
+    ra.trace_belief = o->trace_belief;
+    ra.trace_rewards = o->trace_rewards;
+    const size_t lds = planet_smem_bytes(e->pd.ld);
+    if (!e->planet_lds_attr_set) {
+        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(planet_rollout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)e->lds_max));
+        e->planet_lds_attr_set = true;
+    }
+    const int nwg = (int)((B + kTile - 1) / kTile);
+    hipLaunchKernelGGL(planet_rollout_kernel, dim3(nwg), dim3(kThreads), lds, st, e->pd, ra);
+    HCHECK(hipGetLastError());
+    hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
+    HCHECK(hipGetLastError());
     return 0;
 }
 

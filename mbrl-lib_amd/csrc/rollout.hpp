@@ -322,16 +322,14 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
     }
 }
 
-// One linear layer (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS).
+// One linear op (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS), both with row stride ld.
+// W / bias point at the packed fragments / padded biases of this op (pack_weights_kernel / pack_bias_kernel).
 template <int R>
-__device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
-                                          const float* in, float* out, const int wave, const int lane, Prof& prof) {
-    const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
+__device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
+                                          const int activation, const float slope, const float* in, float* out, const int wave,
+                                          const int lane, Prof& prof) {
     const int KC = lm.Kp / kKChunk;
     const int C = lm.Np / kTile;
-    const float* W = md.w + (size_t)member * md.wmember + lm.woff;
-    const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
-    const bool apply_act = l < md.n_layers - 1;
     const int full = C / kWaves, rem = C % kWaves;
     // leftover units u = (column tile kWaves*full + u / R, row tile u % R), dealt round-robin to waves
     const int nu = rem * R;
@@ -346,19 +344,29 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
     constexpr int kMaxCT = kWaves >= 8 ? 2 : 3;
     int done = 0;
     while (full - done > kMaxCT) {
-        wave_gemm<R, kMaxCT, 0>(in, out, md.ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, md.activation, md.slope, lane, prof);
+        wave_gemm<R, kMaxCT, 0>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
         done += kMaxCT;
     }
     const int c_first = wave + kWaves * done;
     switch (full - done) {
-        case 0: wave_gemm_ex<R, 0>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
-        case 1: wave_gemm_ex<R, 1>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
-        case 2: wave_gemm_ex<R, 2>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof); break;
+        case 0: wave_gemm_ex<R, 0>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+        case 1: wave_gemm_ex<R, 1>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+        case 2: wave_gemm_ex<R, 2>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
         default:
             if constexpr (kMaxCT >= 3)
-                wave_gemm_ex<R, 3>(nex, in, out, md.ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, md.activation, md.slope, lane, prof);
+                wave_gemm_ex<R, 3>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
             break;
     }
+}
+
+// Layer l of the ensemble MLP with member `member`'s weights.
+template <int R>
+__device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
+                                          const float* in, float* out, const int wave, const int lane, Prof& prof) {
+    const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
+    const float* W = md.w + (size_t)member * md.wmember + lm.woff;
+    const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
+    linear_op<R>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
 }
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
@@ -913,8 +921,9 @@ __global__ void export_normals_kernel(float* out, int H, int B, int out_dim, uns
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
 //   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
 // so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
+// src_nk != 0: the source is [E, N, K] row-major (nn.Linear's [out, in]) instead of [E, K, N] (EnsembleLinearLayer).
 __global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
-                                    int Np, long long member_stride, long long layer_off, int permute_cols) {
+                                    int Np, long long member_stride, long long layer_off, int permute_cols, int src_nk) {
     const long long per_member = (long long)Kp * Np;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_member * M) return;
@@ -930,7 +939,7 @@ __global__ void pack_weights_kernel(float* dst, const float* src, const int* mem
     // real column lds_col(m) so that accumulator register i of lane group g lands on LDS position 4g + i
     const int n = 16 * c + (permute_cols ? lds_col(lane & 15) : (lane & 15));
     float v = 0.f;
-    if (k < K && n < N) v = src[((size_t)members[m] * K + k) * N + n];
+    if (k < K && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
     dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
 }
 

@@ -5,7 +5,15 @@ Public names follow mbrl-lib so the stock Hydra configs only swap ``_target_``:
 ``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))``.
 """
 from ._lib import HipetsError, LIB_PATH  # noqa: F401
-from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_checkpoint, spec_from_model_env  # noqa: F401
+from .model import (  # noqa: F401
+    ModelSpec,
+    PlaNetSpec,
+    UnsupportedModelError,
+    model_version,
+    spec_from_checkpoint,
+    spec_from_model_env,
+    spec_from_planet_model,
+)
 from .engine import Engine  # noqa: F401
 from .planning import (  # noqa: F401
     Agent,
@@ -16,6 +24,7 @@ from .planning import (  # noqa: F401
     MPPIOptimizer,
     ModelEnv,
     Optimizer,
+    PlaNetTrajectoryEvalFn,
     TrajectoryOptimizer,
     TrajectoryOptimizerAgent,
     UnfusedTrajectoryEvalFn,

@@ -69,6 +69,20 @@ class IcemParams(C.Structure):
     ]
 
 
+_PLANET_TENSORS = ("w_embed", "b_embed", "w_ih", "b_ih", "w_hh", "b_hh", "w_prior1", "b_prior1", "w_prior2", "b_prior2",
+                   "w_rew1", "b_rew1", "w_rew2", "b_rew2", "w_rew3", "b_rew3")
+
+
+class PlanetDesc(C.Structure):
+    _fields_ = [("latent_size", C.c_int32), ("action_size", C.c_int32), ("belief_size", C.c_int32), ("hidden_size", C.c_int32),
+                ("min_std", C.c_float)] + [(n, C.c_void_p) for n in _PLANET_TENSORS]
+
+
+class PlanetOpts(C.Structure):
+    _fields_ = [("eps", C.c_void_p), ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("no_sample", C.c_int32),
+                ("trace_latent", C.c_void_p), ("trace_belief", C.c_void_p), ("trace_rewards", C.c_void_p)]
+
+
 # every symbol include/hipets.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -95,6 +109,8 @@ SYMBOLS = {
                                    C.c_uint64, C.c_uint64, _P]),
     "hipets_plan_icem": (C.c_int, [_P, C.POINTER(IcemParams), _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64, C.c_uint64,
                                    _P, _P]),
+    "hipets_planet_set_model": (C.c_int, [_P, C.POINTER(PlanetDesc), _P]),
+    "hipets_planet_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PlanetOpts), _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
     "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }

@@ -66,6 +66,7 @@ class Engine:
         _lib.check(self._lib.hipets_create(self.device.index, C.byref(h)))
         self._h = h
         self.spec: Optional[ModelSpec] = None
+        self.planet_spec = None
         self._keep = []  # device tensors that must outlive async set_model work
 
     def close(self):
@@ -437,6 +438,62 @@ class Engine:
                                                   int(bool(has_elite)), _ptr(keep_idx) if keep_idx is not None else None,
                                                   s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
                                                   int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
+    # ---- PlaNet latent planner -----------------------------------------------
+    def planet_set_model(self, spec):
+        """Pack the planning heads of a PlaNet model (``hipets.PlaNetSpec``)."""
+        spec.validate()
+        dev = self.device
+        d = _lib.PlanetDesc()
+        d.latent_size, d.action_size, d.belief_size, d.hidden_size = spec.latent_size, spec.action_size, spec.belief_size, spec.hidden_size
+        d.min_std = float(spec.min_std)
+        keep = []
+        for n in _lib._PLANET_TENSORS:
+            t = getattr(spec, n).detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            setattr(d, n, t.data_ptr())
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_planet_set_model(self._h, C.byref(d), _stream(dev)))
+        self.planet_spec = spec
+
+    def planet_rollout(self, actions: torch.Tensor, latent0: torch.Tensor, belief0: torch.Tensor, num_particles: int, *,
+                       eps: Optional[torch.Tensor] = None, sample: bool = True, seed: int = 0, stream_id: int = 0,
+                       trace_latent: Optional[torch.Tensor] = None, trace_belief: Optional[torch.Tensor] = None,
+                       trace_rewards: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ModelEnv.evaluate_action_sequences on the PlaNet model (model_env.py:145-191): actions [pop, H, A]; latent0 /
+        belief0 = the saved posterior sample / belief ([latent] / [belief], any leading 1s) on the device."""
+        spec = getattr(self, "planet_spec", None)
+        if spec is None:
+            raise HipetsError("Engine.planet_set_model() has not been called")
+        dev = self.device
+        if actions.ndim != 3:
+            raise ValueError("action_sequences must be [B, H, A]")
+        _check_dev(actions, torch.float32, dev, "action_sequences")
+        pop, H, A = actions.shape
+        if A != spec.action_size:
+            raise ValueError(f"action dim {A} != model action_size {spec.action_size}")
+        _check_dev(latent0, torch.float32, dev, "latent0", numel=spec.latent_size)
+        _check_dev(belief0, torch.float32, dev, "belief0", numel=spec.belief_size)
+        B = pop * num_particles
+        o = _lib.PlanetOpts()
+        o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
+        o.no_sample = int(not sample)
+        if eps is not None:
+            _check_dev(eps, torch.float32, dev, "eps", (H, B, spec.latent_size))
+            o.eps = _ptr(eps)
+        for name, t, width in (("trace_latent", trace_latent, spec.latent_size), ("trace_belief", trace_belief, spec.belief_size),
+                               ("trace_rewards", trace_rewards, None)):
+            if t is not None:
+                _check_dev(t, torch.float32, dev, name, (H, B) if width is None else (H, B, width))
+                setattr(o, name, _ptr(t))
+        if out is None:
+            out = torch.empty(pop, dtype=torch.float32, device=dev)
+        else:
+            _check_dev(out, torch.float32, dev, "out", (pop,))
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_planet_rollout(self._h, _ptr(actions), _ptr(latent0), _ptr(belief0), pop, H, num_particles,
+                                                       C.byref(o), _ptr(out), _stream(dev)))
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------------

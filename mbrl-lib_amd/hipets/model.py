@@ -264,3 +264,92 @@ def spec_from_checkpoint(model_dir, obs_dim: int, act_dim: int, **spec_kwargs) -
                      elite_models=list(elite) if elite is not None else None, deterministic=deterministic, **kw)
     spec.validate()
     return spec
+
+
+# ---------------------------------------------------------------------------------------------
+# PlaNet latent planner
+# ---------------------------------------------------------------------------------------------
+PLANET_TENSORS = ("w_embed", "b_embed", "w_ih", "b_ih", "w_hh", "b_hh", "w_prior1", "b_prior1", "w_prior2", "b_prior2",
+                  "w_rew1", "b_rew1", "w_rew2", "b_rew2", "w_rew3", "b_rew3")
+
+
+@dataclass
+class PlaNetSpec:
+    """The tensors ``PlaNetModel.sample`` reads (mbrl/models/planet.py:531-581), nn.Linear layout ([out, in] / [out])."""
+
+    w_embed: torch.Tensor  # belief_model.embedding_layer[0]
+    b_embed: torch.Tensor
+    w_ih: torch.Tensor  # belief_model.rnn (GRUCell), gates r | z | n
+    b_ih: torch.Tensor
+    w_hh: torch.Tensor
+    b_hh: torch.Tensor
+    w_prior1: torch.Tensor  # prior_transition_model[0], [2]
+    b_prior1: torch.Tensor
+    w_prior2: torch.Tensor
+    b_prior2: torch.Tensor
+    w_rew1: torch.Tensor  # reward_model[0], [2], [4]
+    b_rew1: torch.Tensor
+    w_rew2: torch.Tensor
+    b_rew2: torch.Tensor
+    w_rew3: torch.Tensor
+    b_rew3: torch.Tensor
+    min_std: float = 0.1
+
+    @property
+    def latent_size(self) -> int:
+        return int(self.w_prior2.shape[0]) // 2
+
+    @property
+    def belief_size(self) -> int:
+        return int(self.w_hh.shape[1])
+
+    @property
+    def action_size(self) -> int:
+        return int(self.w_embed.shape[1]) - self.latent_size
+
+    @property
+    def hidden_size(self) -> int:
+        return int(self.w_prior1.shape[0])
+
+    def flops_per_candidate_step(self) -> int:
+        return 2 * sum(int(getattr(self, n).shape[0]) * int(getattr(self, n).shape[1]) for n in PLANET_TENSORS if n[0] == "w")
+
+    def validate(self):
+        L, A, Hb, F = self.latent_size, self.action_size, self.belief_size, self.hidden_size
+        want = {"w_embed": (Hb, L + A), "b_embed": (Hb,), "w_ih": (3 * Hb, Hb), "b_ih": (3 * Hb,), "w_hh": (3 * Hb, Hb), "b_hh": (3 * Hb,),
+                "w_prior1": (F, Hb), "b_prior1": (F,), "w_prior2": (2 * L, F), "b_prior2": (2 * L,), "w_rew1": (F, Hb + L), "b_rew1": (F,),
+                "w_rew2": (F, F), "b_rew2": (F,), "w_rew3": (1, F), "b_rew3": (1,)}
+        if A < 1 or L < 1:
+            raise UnsupportedModelError("PlaNet heads have inconsistent sizes")
+        for n, shp in want.items():
+            if tuple(getattr(self, n).shape) != shp:
+                raise UnsupportedModelError(f"PlaNet tensor {n} has shape {tuple(getattr(self, n).shape)}, expected {shp}")
+
+
+def is_planet_model(model) -> bool:
+    return all(hasattr(model, a) for a in ("belief_model", "prior_transition_model", "reward_model", "latent_state_size"))
+
+
+def spec_from_planet_model(model) -> PlaNetSpec:
+    """Read a live ``mbrl.models.PlaNetModel`` (planet.py:196-272); tensors are references to the live parameters."""
+    if not is_planet_model(model):
+        raise UnsupportedModelError("not a PlaNetModel")
+    bm, pr, rw = model.belief_model, model.prior_transition_model, model.reward_model
+    if type(bm.embedding_layer[1]).__name__ != "ReLU" or type(pr[1]).__name__ != "ReLU" or type(rw[1]).__name__ != "ReLU":
+        raise UnsupportedModelError("PlaNet heads with a non-ReLU activation have no fused implementation")
+    d = lambda t: t.detach()  # noqa: E731
+    spec = PlaNetSpec(
+        w_embed=d(bm.embedding_layer[0].weight), b_embed=d(bm.embedding_layer[0].bias),
+        w_ih=d(bm.rnn.weight_ih), b_ih=d(bm.rnn.bias_ih), w_hh=d(bm.rnn.weight_hh), b_hh=d(bm.rnn.bias_hh),
+        w_prior1=d(pr[0].weight), b_prior1=d(pr[0].bias), w_prior2=d(pr[2].weight), b_prior2=d(pr[2].bias),
+        w_rew1=d(rw[0].weight), b_rew1=d(rw[0].bias), w_rew2=d(rw[2].weight), b_rew2=d(rw[2].bias),
+        w_rew3=d(rw[4].weight), b_rew3=d(rw[4].bias), min_std=float(model.min_std),
+    )
+    spec.validate()
+    return spec
+
+
+def planet_version(model) -> tuple:
+    """Freshness token of the planning heads (PlaNetModel.update rewrites them in place, planet.py:485-519)."""
+    mods = (model.belief_model, model.prior_transition_model, model.reward_model)
+    return tuple(int(p._version) for m in mods for p in m.parameters())

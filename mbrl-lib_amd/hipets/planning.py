@@ -23,7 +23,8 @@ import torch
 
 from ._lib import HipetsError, IcemParams
 from .engine import Engine
-from .model import ModelSpec, UnsupportedModelError, model_version, spec_from_model_env
+from .model import (ModelSpec, PlaNetSpec, UnsupportedModelError, is_planet_model, model_version, planet_version,
+                    spec_from_model_env, spec_from_planet_model)
 
 _ENGINES: Dict[int, Engine] = {}
 
@@ -345,10 +346,82 @@ class UnfusedTrajectoryEvalFn:
         return total.reshape(-1, P).mean(dim=1)
 
 
+class PlaNetTrajectoryEvalFn:
+    """``trajectory_eval_fn`` for a PlaNet latent model: ``ModelEnv.evaluate_action_sequences`` with
+    ``PlaNetModel.sample`` as the transition (mbrl/models/planet.py:531-581, mbrl/algorithms/planet.py), the whole horizon in
+    one kernel launch.  Like the reference, the observation argument only fixes the batch size: rollouts start from the
+    model's saved posterior sample and belief (``update_posterior``, planet.py:600-640), read from the live model at every
+    call, or set with :meth:`set_state` when built from a ``PlaNetSpec``.
+
+    ``mode='fast'``: in-kernel Philox draws; ``mode='exact'``: the reference's draws (one ``randn([B, latent])`` per step
+    from the generator) made on the host and injected."""
+
+    def __init__(self, model, num_particles: int = 1, engine: Optional[Engine] = None, mode: str = "fast", seed: int = 0,
+                 device=None, rng: Optional[torch.Generator] = None):
+        self.num_particles, self.mode, self.seed, self.calls = int(num_particles), mode, int(seed), 0
+        self._planet, self._version, self._state = None, None, None
+        if isinstance(model, PlaNetSpec):
+            spec, dev = model, (device if device is not None else "cuda:0")
+        else:
+            planet = getattr(model, "dynamics_model", model)  # a ModelEnv or the PlaNetModel itself
+            self._planet = planet
+            spec = spec_from_planet_model(planet)
+            self._version = planet_version(planet)
+            dev = device if device is not None else getattr(planet, "device", "cuda:0")
+            if rng is None:
+                rng = getattr(model, "_rng", None)
+        self.engine = engine if engine is not None else get_engine(dev)
+        self.device = self.engine.device
+        self.spec = spec
+        self._rng = rng
+        self.engine.planet_set_model(spec)
+
+    def set_state(self, latent: torch.Tensor, belief: torch.Tensor):
+        """The posterior sample s_t and belief h_t rollouts start from ([1, latent] / [1, belief])."""
+        self._state = (latent.detach().to(self.device, torch.float32).reshape(-1).contiguous(),
+                       belief.detach().to(self.device, torch.float32).reshape(-1).contiguous())
+
+    def refresh(self):
+        if self._planet is not None and planet_version(self._planet) != self._version:
+            self.spec = spec_from_planet_model(self._planet)
+            self.engine.planet_set_model(self.spec)
+            self._version = planet_version(self._planet)
+
+    def __call__(self, initial_state, action_sequences: torch.Tensor) -> torch.Tensor:
+        self.refresh()
+        if self.engine.planet_spec is not self.spec:
+            self.engine.planet_set_model(self.spec)
+        if self._planet is not None:  # planet.py:669-672
+            if self._planet._current_posterior_sample is None or self._planet._current_belief is None:
+                raise RuntimeError("PlaNetModel has no saved posterior: call update_posterior() before planning")
+            self.set_state(self._planet._current_posterior_sample, self._planet._current_belief)
+        if self._state is None:
+            raise RuntimeError("no latent state: call set_state(latent, belief) first")
+        a = action_sequences
+        if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        self.calls += 1
+        latent0, belief0 = self._state
+        if self.mode == "fast":
+            return self.engine.planet_rollout(a, latent0, belief0, self.num_particles, seed=self.seed, stream_id=self.calls)
+        pop, H, _ = a.shape
+        B = pop * self.num_particles
+        if self._rng is None:
+            self._rng = torch.Generator().manual_seed(self.seed)
+        if self._rng.device.type == "cpu":
+            eps = torch.stack([torch.randn(B, self.spec.latent_size, generator=self._rng) for _ in range(H)]).to(self.device)
+        else:
+            eps = torch.stack([torch.randn(B, self.spec.latent_size, generator=self._rng, device=self._rng.device) for _ in range(H)])
+            eps = eps.to(self.device)
+        return self.engine.planet_rollout(a, latent0, belief0, self.num_particles, eps=eps.contiguous())
+
+
 def make_eval_fn(model, num_particles: int, **kw):
     """``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))`` on a stock or a
     hipets agent (seam 3 of SURVEY.md section 8b).  Returns the fully fused objective when reward / termination are
     mbrl.env closed forms, the unfused one (fused model step + Python callables) when they are arbitrary callables."""
+    if isinstance(model, PlaNetSpec) or is_planet_model(getattr(model, "dynamics_model", model)):
+        return PlaNetTrajectoryEvalFn(model, num_particles, **kw)
     try:
         return HipTrajectoryEvalFn(model, num_particles, **kw)
     except UnsupportedModelError:

@@ -50,6 +50,8 @@ def test_struct_layouts_match_header_field_order():
     assert fields("hipets_rollout_opts") == [f[0] for f in _lib.RolloutOpts._fields_]
     assert fields("hipets_cem_params") == [f[0] for f in _lib.CemParams._fields_]
     assert fields("hipets_icem_params") == [f[0] for f in _lib.IcemParams._fields_]
+    assert fields("hipets_planet_desc") == [f[0] for f in _lib.PlanetDesc._fields_]
+    assert fields("hipets_planet_opts") == [f[0] for f in _lib.PlanetOpts._fields_]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")

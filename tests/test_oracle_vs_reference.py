@@ -308,3 +308,25 @@ def test_planet_rollout_bitwise_vs_reference(mbrl, P):
                                                 rng=torch.Generator().manual_seed(8))
         o_lat, o_rew, o_bel = pl.planet_step(pm, lat, bel, act, generator=torch.Generator().manual_seed(8), deterministic=det)
         assert torch.equal(r_lat, o_lat) and torch.equal(r_rew, o_rew) and torch.equal(r_state["belief"], o_bel)
+
+
+def test_planet_spec_extraction_from_live_reference_model(mbrl):
+    """hipets.spec_from_planet_model reads the live PlaNetModel's planning heads; the freshness token follows updates."""
+    import hipets
+    from hipets.model import planet_version
+    from oracle import planet_oracle as pl
+    from oracle.ref_bridge import build_reference_planet_env
+
+    pm = pl.make_synthetic_planet(latent=10, action=3, belief=24, hidden=20, seed=6)
+    me, model = build_reference_planet_env(pm, torch.zeros(1, 10), torch.zeros(1, 24))
+    for source in (model, me):  # the model itself or the ModelEnv wrapping it
+        spec = hipets.spec_from_planet_model(getattr(source, "dynamics_model", source))
+        assert (spec.latent_size, spec.action_size, spec.belief_size, spec.hidden_size) == (10, 3, 24, 20)
+        for n in pl.PLANET_TENSORS:
+            assert torch.equal(getattr(spec, n), getattr(pm, n)), n
+        assert spec.min_std == pytest.approx(pm.min_std)
+    assert spec.flops_per_candidate_step() == pm.flops_per_candidate_step()
+    v0 = planet_version(model)
+    with torch.no_grad():
+        model.reward_model[2].weight.mul_(0.5)
+    assert planet_version(model) != v0
