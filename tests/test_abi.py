@@ -78,3 +78,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "pets_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_header_is_plain_c_and_the_c_client_links():
+    """include/hipets.h compiles as C99 with -Wall -Wextra -Werror and a C program links against libhipets.so
+    (no C++ or torch types in any signature)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    ge.build_c_client(force=True)
+    assert os.path.exists(ge.C_CLIENT)
