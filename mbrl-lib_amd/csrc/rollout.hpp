@@ -143,15 +143,19 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 
     const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
     const int exr[kMaxExtras] = {ex.r0, ex.r1, ex.r2, ex.r3};
-    // 32-bit element offsets from W (a member's layer block is < 2^31 floats)
-    int woff[CTn], wxoff[EXn], axoff[EXn];
+    // per-lane BYTE offsets from the (wave-uniform) chunk base W + 256 kk floats: loop invariant, unsigned 32 bit, so the
+    // loads take the scalar-base form (global_load v, v_off, s[base]) and the k loop carries no 64-bit address VALU work
+    // (a wave's own VALU instructions do not overlap its MFMAs, profiles/microbench)
+    unsigned woff[CTn], wxoff[EXn];
+    int axoff[EXn];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) woff[ct] = ((c_first + kWaves * ct) * KC * 64 + lane) * 4;
+    for (int ct = 0; ct < CT; ++ct) woff[ct] = (unsigned)(((c_first + kWaves * ct) * KC * 64 + lane) * 16);
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
-        wxoff[e] = (exc[e] * KC * 64 + lane) * 4;
+        wxoff[e] = (unsigned)((exc[e] * KC * 64 + lane) * 16);
         axoff[e] = exr[e] * 16 * ld;
     }
+    const char* Wb = reinterpret_cast<const char*>(W);
     const float* ap = in + (lane & 15) * ld + 4 * (lane >> 4);
     // biases of this lane's columns: loaded before the k loop so their latency hides behind it
     f32x4 bv[CTn], bvx[EXn];
@@ -168,10 +172,11 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
+        const char* Wk = Wb + (size_t)kk * 1024;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(W + woff[ct] + kk * 256);
+        for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(Wk + woff[ct]);
 #pragma unroll
-        for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(W + wxoff[e] + kk * 256);
+        for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(Wk + wxoff[e]);
 #pragma unroll
         for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + kk * 16);
 #pragma unroll
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         int member = 0;
         for (int mi = 0; mi < n_run; ++mi) {
             if (expectation) member = mi;
-            else if (fast) member = sm.sched[t];
+            else if (fast) member = __builtin_amdgcn_readfirstlane(sm.sched[t]);  // wave-uniform: weight pointers stay in SGPRs
             else member = domain;
             if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
                 build_input(t);
