@@ -72,6 +72,7 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
 // dimensions d of the [H,A] plan and reduces the K elites in f64.
 constexpr int kRefitThreads = 1024;
 constexpr int kMaxPop = 8192;
+constexpr int kRankSortMax = 2048;  // up to here the O(n^2 / threads) rank count beats the bitonic network
 
 __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* values, const float* population, float* mu,
                                                                  float* disp, float* best_value, float* best_solution,
@@ -102,7 +103,31 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         idx[i] = i < p.pop ? i : 0x7FFFFFFF;
     }
     __syncthreads();
-    // bitonic sort, "a before b" iff (key_a > key_b) or (equal and idx_a < idx_b)
+    // order: "a before b" iff (key_a > key_b) or (equal and idx_a < idx_b)
+    if (n2 <= kRankSortMax) {
+        // small populations (every PETS config): rank by counting -- element i sits at position #{j before i}.  One pass of
+        // pop LDS broadcast reads per element and a single barrier instead of the ~log^2(n)/2 barrier stages of the
+        // network below (45 for pop 500); only the first K positions (the elites) and position 0 (the best) are consumed.
+        for (int i = tid; i < p.pop; i += kRefitThreads) {
+            const float ki = key[i];
+            int rank = 0;
+            for (int j = 0; j < p.pop; ++j) {
+                const float kj = key[j];
+                rank += (kj > ki) || (kj == ki && j < i);
+            }
+            idx[i] = rank;  // idx[] holds ranks for now (it held the identity so far)
+        }
+        __syncthreads();
+        // scatter: sorted position -> element; ranks are a permutation of 0..pop-1
+        int* pos = reinterpret_cast<int*>(smem + (size_t)n2 * 8);  // reuses the refit scratch (free until the barrier below)
+        for (int i = tid; i < p.pop; i += kRefitThreads) pos[idx[i]] = i;
+        __syncthreads();
+        float top_key = key[pos[0]];
+        __syncthreads();
+        for (int i = tid; i < p.pop; i += kRefitThreads) idx[i] = pos[i];
+        if (tid == 0) key[0] = top_key;  // key[] is only consulted at position 0 from here on
+        __syncthreads();
+    } else
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < n2; i += kRefitThreads) {
@@ -130,21 +155,46 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     const int top_i = idx[0];
     __syncthreads();
 
-    for (int d = tid; d < p.D; d += kRefitThreads) {
+    // elite mean / variance: `parts` threads share a dimension (each owns every parts-th elite, independent loads in
+    // flight), partial sums meet in LDS; consecutive threads own consecutive dimensions (coalesced rows).  f64 throughout.
+    double* red = reinterpret_cast<double*>(smem + (size_t)n2 * 8);  // [kRefitThreads]
+    int parts = kRefitThreads / p.D;
+    parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+    const int G = kRefitThreads / parts;  // dimensions per sweep
+    const int part = tid / G, dloc = tid % G;
+    for (int base = 0; base < p.D; base += G) {
+        const int d = base + dloc;
+        const bool live = d < p.D && part < parts;
         double s = 0.0;
-        for (int k = 0; k < p.K; ++k) s += (double)population[(size_t)idx[k] * p.D + d];
-        const double mean = s / (double)p.K;
-        double ss = 0.0;
-        for (int k = 0; k < p.K; ++k) {
-            const double dv = (double)population[(size_t)idx[k] * p.D + d] - mean;
-            ss += dv * dv;
+        if (live)
+            for (int k = part; k < p.K; k += parts) s += (double)population[(size_t)idx[k] * p.D + d];
+        red[tid] = s;
+        __syncthreads();
+        double mean = 0.0;
+        if (live) {
+            for (int q = 0; q < parts; ++q) mean += red[q * G + dloc];
+            mean /= (double)p.K;
         }
-        double var = ss / (double)(p.unbiased ? (p.K - 1) : p.K);
-        const float new_mu = (float)mean;
-        const float new_disp = p.clipped ? (float)sqrt(var) : (float)var;  // :134-137
-        mu[d] = p.alpha * mu[d] + p.one_minus_alpha * new_mu;               // :138
-        disp[d] = p.alpha * disp[d] + p.one_minus_alpha * new_disp;         // :139
-        if (improved) best_solution[d] = population[(size_t)top_i * p.D + d];
+        __syncthreads();
+        double ss = 0.0;
+        if (live)
+            for (int k = part; k < p.K; k += parts) {
+                const double dv = (double)population[(size_t)idx[k] * p.D + d] - mean;
+                ss += dv * dv;
+            }
+        red[tid] = ss;
+        __syncthreads();
+        if (live && part == 0) {
+            double var = 0.0;
+            for (int q = 0; q < parts; ++q) var += red[q * G + dloc];
+            var /= (double)(p.unbiased ? (p.K - 1) : p.K);
+            const float new_mu = (float)mean;
+            const float new_disp = p.clipped ? (float)sqrt(var) : (float)var;  // :134-137
+            mu[d] = p.alpha * mu[d] + p.one_minus_alpha * new_mu;               // :138
+            disp[d] = p.alpha * disp[d] + p.one_minus_alpha * new_disp;         // :139
+            if (improved) best_solution[d] = population[(size_t)top_i * p.D + d];
+        }
+        __syncthreads();
     }
     if (improved && tid == 0) best_value[0] = top;
 }

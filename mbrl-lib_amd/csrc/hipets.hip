@@ -1,5 +1,6 @@
 // hipets.hip -- C-ABI implementation (see include/hipets.h).  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -72,7 +73,7 @@ struct hipets_engine {
     int ensemble_size = 0;
     DevBuf wpack, bpack, layer_meta, norm_mean, norm_std, min_lv, max_lv, no_delta, members;
     // rollout workspace
-    DevBuf s0, state, totals, term, schedule;
+    DevBuf s0, state, totals, term, schedule, plan_schedule;
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
     // PlaNet latent model
@@ -106,14 +107,15 @@ int launch_rollout_r(hipets_engine* e, int grid, size_t lds, const RolloutArgs& 
             HCHECK(hipEventCreate(&a));
             HCHECK(hipEventCreate(&b));
         }
-        HCHECK(hipEventRecord(a, st));
+        // the events ride on the dispatch packet itself (start / end timestamps of THIS kernel): no extra barrier
+        // packets around the launch, so timing does not perturb the plan it measures
+        hipExtLaunchKernelGGL(rollout_kernel<R>, dim3(grid), dim3(kThreads), (std::uint32_t)lds, st, a, b, 0u, e->md, ra);
+        HCHECK(hipGetLastError());
+        e->events.emplace_back(a, b);
+        return 0;
     }
     hipLaunchKernelGGL(rollout_kernel<R>, dim3(grid), dim3(kThreads), lds, st, e->md, ra);
     HCHECK(hipGetLastError());
-    if (e->timing) {
-        HCHECK(hipEventRecord(b, st));
-        e->events.emplace_back(a, b);
-    }
     return 0;
 }
 
@@ -161,6 +163,31 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         }
     }
     return best;
+}
+
+// Plan-level prologue shared by the fused plans: stage the observation(s) once and, for member-sampling propagation,
+// generate the member schedules of `iters` consecutive FAST rollouts (stream ids first_stream, +1, ...) of `pop` candidates
+// in ONE launch.  *sched = schedule of rollout 0 (rollout i: + i * H * nwg) or nullptr (expectation propagation).
+int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, int H, int iters, uint64_t seed, uint64_t first_stream,
+                  hipStream_t st, const int** sched, size_t* sched_stride) {
+    const ModelDev& md = e->md;
+    if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
+    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    *sched = nullptr;
+    *sched_stride = 0;
+    if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1) return 0;
+    const long long tiles = (pop + kTile - 1) / kTile;
+    const int R = choose_R(e, tiles, P, 0, H);
+    const int nwg = (int)((tiles + R - 1) / R) * P;
+    if (nwg > 8000) return 0;  // the rollout reports the error
+    if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
+    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, iters), dim3(256), (size_t)nwg * 8, st, e->plan_schedule.as<int>(), nwg, md.M,
+                       md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)seed,
+                       (unsigned long long)first_stream);
+    HCHECK(hipGetLastError());
+    *sched = e->plan_schedule.as<int>();
+    *sched_stride = (size_t)H * nwg;
+    return 0;
 }
 
 CemDev make_cem(const hipets_cem_params* p, int n_env = 1) {
@@ -225,7 +252,7 @@ void hipets_destroy(hipets_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
-                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->mu, &e->disp, &e->population, &e->values,
+                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->mu, &e->disp, &e->population, &e->values,
                       &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -364,10 +391,31 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+// hipets_rollout with two plan-level shortcuts: s0 == nullptr means the initial state(s) are already staged in e->s0
+// (the observation is the same for every iteration of a plan), `presched` is a member schedule [H, n_workgroups] the
+// plan generated up front for this rollout (one launch for all iterations instead of one per rollout).
+int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
+                 const hipets_rollout_opts* o, float* returns, void* stream, const int* presched);
+}
+
+extern "C" {
+
 int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
                    const hipets_rollout_opts* o, float* returns, void* stream) {
+    if (!s0) return fail("null argument");
+    return rollout_impl(e, actions, s0, pop, H, P, o, returns, stream, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
+                 const hipets_rollout_opts* o, float* returns, void* stream, const int* presched) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
-    if (!actions || !s0 || !o || !returns) return fail("null argument");
+    if (!actions || !o || !returns) return fail("null argument");
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
@@ -381,7 +429,7 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         return fail("n_env %d needs FAST mode and a population (%d) divisible by it", n_env, pop);
     if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
     if (e->totals.ensure((size_t)B * 4)) return 1;
-    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    if (s0) HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
 
     RolloutArgs ra{};
     ra.pop = pop; ra.P = P; ra.H = H; ra.B = (int)B;
@@ -445,6 +493,8 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
         if (md.propagation != HIPETS_PROP_EXPECTATION) {
             if (o->member_schedule) {
                 ra.schedule = o->member_schedule;
+            } else if (presched) {
+                ra.schedule = presched;
             } else {
                 if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
                 hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
@@ -464,6 +514,10 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     HCHECK(hipGetLastError());
     return 0;
 }
+
+}  // namespace
+
+extern "C" {
 
 int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t B, const hipets_rollout_opts* o, float* next_obs,
                 float* rewards, uint8_t* dones, void* stream) {
@@ -592,7 +646,7 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
     const CemDev c = make_cem(p);
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8, reinterpret_cast<hipStream_t>(stream), c,
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, elite_idx);
     HCHECK(hipGetLastError());
     return 0;
@@ -691,6 +745,11 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     ro.n_env = n_env;
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
+    const int* sched = nullptr;
+    size_t sched_stride = 0;
+    if (plan_prologue(e, s0, n_env, (int)npop, P, c.H, p->num_iterations, seed, plan_id * (uint64_t)p->num_iterations, st, &sched,
+                      &sched_stride))
+        return 1;
     for (int i = 0; i < p->num_iterations; ++i) {
         const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
         const long long n = (long long)npop * c.D;
@@ -699,8 +758,10 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
                            e->population.as<float>());
         HCHECK(hipGetLastError());
         ro.stream_id = sid;
-        if (hipets_rollout(e, e->population.as<float>(), s0, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream)) return 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8, st, c, e->values.as<float>(),
+        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream,
+                         sched ? sched + (size_t)i * sched_stride : nullptr))
+            return 1;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), (int*)nullptr);
         HCHECK(hipGetLastError());
@@ -730,13 +791,18 @@ int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_
     hipets_rollout_opts ro{};
     ro.mode = HIPETS_MODE_FAST;
     ro.seed = seed;
+    const int* sched = nullptr;
+    size_t sched_stride = 0;
+    if (plan_prologue(e, s0, 1, pop, P, H, num_iterations, seed, plan_id * (uint64_t)num_iterations, st, &sched, &sched_stride)) return 1;
     for (int k = 0; k < num_iterations; ++k) {
         const uint64_t sid = plan_id * (uint64_t)num_iterations + (uint64_t)k;
         if (hipets_mppi_sample(e, pop, H, A, beta, mean, e->past_action.as<float>(), lower, upper, nullptr, seed, sid,
                                e->population.as<float>(), stream))
             return 1;
         ro.stream_id = sid;
-        if (hipets_rollout(e, e->population.as<float>(), s0, pop, H, P, &ro, e->values.as<float>(), stream)) return 1;
+        if (rollout_impl(e, e->population.as<float>(), nullptr, pop, H, P, &ro, e->values.as<float>(), stream,
+                         sched ? sched + (size_t)k * sched_stride : nullptr))
+            return 1;
         if (hipets_mppi_update(e, pop, H, A, gamma, e->values.as<float>(), e->population.as<float>(), mean, stream)) return 1;
     }
     return 0;
@@ -825,7 +891,7 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         if (check_cem(&cp)) return 1;
         int n2 = 1;
         while (n2 < rows) n2 <<= 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8, st, make_cem(&cp), e->values.as<float>(), popbuf,
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, st, make_cem(&cp), e->values.as<float>(), popbuf,
                            e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(), e->best_solution.as<float>(),
                            e->elite_idx.as<int>());
         HCHECK(hipGetLastError());

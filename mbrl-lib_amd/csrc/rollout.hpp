@@ -886,6 +886,9 @@ __global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, in
                                        unsigned long long stream_id) {
     extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
     const int t = blockIdx.x;
+    // blockIdx.y: consecutive rollouts of one plan (stream ids stream_id, stream_id + 1, ...), schedules back to back
+    stream_id += blockIdx.y;
+    sched += (size_t)blockIdx.y * gridDim.x * nwg;
     const unsigned long long tk = fixed ? 0xFFFFFFFFull : (unsigned long long)t;
     const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
     for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
