@@ -34,6 +34,10 @@ def gather_values(local: torch.Tensor, pop: int, group=None) -> torch.Tensor:
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} values, expected {hi - lo}")
     backend = dist.get_backend(group)
+    if backend == "nccl" and pop % world == 0 and local.is_contiguous():
+        out = torch.empty(pop, dtype=local.dtype, device=local.device)  # even shards: the collective writes the result in place
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
     # gloo (CPU tests, or several ranks sharing one GPU in the single-GPU smoke test) gathers through host memory
     comm_dev = local.device if backend == "nccl" else torch.device("cpu")
     send = torch.zeros(width, dtype=local.dtype, device=comm_dev)
