@@ -10,7 +10,7 @@ ranks with no broadcast.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is us
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import numpy as np
 import torch

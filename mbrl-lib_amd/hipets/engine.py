@@ -3,7 +3,7 @@ device memory and streams; every computation is a libhipets call."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch

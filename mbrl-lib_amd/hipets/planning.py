@@ -223,10 +223,8 @@ class ModelEnv:
             if self.mode == "exact":
                 self._fixed_perm = torch.randperm(B).to(self.device)
             else:
-                tiles = -(-B // 16)
                 nwg, _ = self.engine.fast_geometry(B, 1, 1)
                 self._fixed_schedule = self.engine.fast_schedule(1, nwg, self.seed, self._steps + 1).contiguous()
-                del tiles
         return {"obs": obs, "propagation_indices": self._fixed_perm}
 
     def step(self, actions, model_state: Dict[str, torch.Tensor], sample: bool = False):
