@@ -277,36 +277,50 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // accumulator holds 4 CONSECUTIVE LDS columns (16c + 4g .. +3; the weight / bias packing pre-permutes the real
     // columns so that this holds in the chunk-transposed layout too) of batch row 16r + (lane & 15): one
     // ds_write_b128 per accumulator instead of four ds_write_b32.
+    // actfn maps the 4 accumulator values of a lane at once (lets an activation use packed 2 x f32 VALU instructions:
+    // a wave's VALU work is not hidden behind anything here, so the instruction count is the cost)
     auto store = [&](auto actfn) __attribute__((always_inline)) {
         const int j = lane & 15, g4 = 4 * (lane >> 4);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int col = (c_first + kWaves * ct) * 16 + g4;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                f32x4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = actfn(acc[ct][r][i]);
-                *reinterpret_cast<f32x4*>(out + (r * 16 + j) * ld + col) = v;
-            }
+            for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(out + (r * 16 + j) * ld + col) = actfn(acc[ct][r]);
         }
 #pragma unroll
-        for (int e = 0; e < EX; ++e) {
+        for (int e = 0; e < EX; ++e) *reinterpret_cast<f32x4*>(out + (exr[e] * 16 + j) * ld + exc[e] * 16 + g4) = actfn(accx[e]);
+    };
+    auto each = [](auto f) {  // lift a scalar activation to the 4 values
+        return [f](const f32x4 a) {
             f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = actfn(accx[e][i]);
-            *reinterpret_cast<f32x4*>(out + (exr[e] * 16 + j) * ld + exc[e] * 16 + g4) = v;
-        }
+            for (int i = 0; i < 4; ++i) v[i] = f(a[i]);
+            return v;
+        };
     };
     if (!apply_act) {
-        store([](float x) { return x; });
+        store([](const f32x4 a) { return a; });
     } else {
         switch (act) {
-            case HIPETS_ACT_SILU: store([](float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }); break;
-            case HIPETS_ACT_RELU: store([](float x) { return fmaxf(x, 0.0f); }); break;
-            case HIPETS_ACT_LEAKY_RELU: store([slope](float x) { return x > 0.0f ? x : slope * x; }); break;
-            case HIPETS_ACT_TANH: store([](float x) { return tanhf(x); }); break;
-            default: store([](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }); break;
+            case HIPETS_ACT_SILU:  // x * rcp(1 + exp2(-x log2 e)): the two multiplies and the add as packed 2 x f32 ops
+                store([](const f32x4 a) {
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    const f32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
+                    const f32x2 lo = {a[0], a[1]}, hi = {a[2], a[3]};
+                    f32x2 tl = lo * k, th = hi * k;
+                    tl[0] = __builtin_amdgcn_exp2f(tl[0]); tl[1] = __builtin_amdgcn_exp2f(tl[1]);
+                    th[0] = __builtin_amdgcn_exp2f(th[0]); th[1] = __builtin_amdgcn_exp2f(th[1]);
+                    tl = tl + one; th = th + one;
+                    tl[0] = __builtin_amdgcn_rcpf(tl[0]); tl[1] = __builtin_amdgcn_rcpf(tl[1]);
+                    th[0] = __builtin_amdgcn_rcpf(th[0]); th[1] = __builtin_amdgcn_rcpf(th[1]);
+                    const f32x2 yl = lo * tl, yh = hi * th;
+                    return f32x4{yl[0], yl[1], yh[0], yh[1]};
+                });
+                break;
+            case HIPETS_ACT_RELU: store(each([](float x) { return fmaxf(x, 0.0f); })); break;
+            case HIPETS_ACT_LEAKY_RELU: store(each([slope](float x) { return x > 0.0f ? x : slope * x; })); break;
+            case HIPETS_ACT_TANH: store(each([](float x) { return tanhf(x); })); break;
+            default: store(each([](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); })); break;
         }
     }
     prof.mark(13);
