@@ -478,3 +478,51 @@ def test_fused_icem_draws_its_own_kept_elites(engine):
     rand = (torch.rand(8, H, act, generator=g) * 2 - 1).to(DEV)
     vals = obj(torch.cat([p2[None], rand]).contiguous())
     assert vals[0] > vals[1:].median()  # the refined plan beats typical random plans under the same deterministic model
+
+
+def test_full_plan_reference_order_same_elites_and_action(engine):
+    """North-star parity at plan level: a whole CEM plan with the model rollout as objective, every random draw injected
+    (truncated normals of the sampler, per-step randperms and eps of the rollouts: what the reference consumes under
+    fixed seeds).  The engine must select the SAME elites at every iteration (T3, up to value ties within T2) and return
+    the same plan / first action as the oracle (T4)."""
+    obs, act, H, P, pop, iters = 17, 6, 8, 5, 60, 4
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=12, no_delta_list=[0])
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(4)
+    s0 = (np.random.default_rng(2).standard_normal(obs) * 0.1).astype(np.float32)
+    B = pop * P
+    z = [po.truncated_normal_(torch.zeros(pop, H, act), generator=g) for _ in range(iters)]
+    perms = [torch.stack([torch.randperm(B, generator=g) for _ in range(H)]) for _ in range(iters)]
+    eps = [torch.randn(H, B, obs, generator=g) for _ in range(iters)]
+    lower, upper = -torch.ones(H, act), torch.ones(H, act)
+
+    calls = {"n": 0}
+
+    def oracle_obj(population):
+        i = calls["n"]; calls["n"] += 1
+        return po.rollout(om, population, s0, P, perms=perms[i], eps=eps[i])
+
+    rec = []
+    ref = po.cem_optimize(oracle_obj, torch.zeros(H, act), lower, upper, iters, 0.1, pop, 0.1, return_mean_elites=True, noise=z, record=rec)
+
+    dcalls = {"n": 0}
+
+    def engine_obj(population):
+        i = dcalls["n"]; dcalls["n"] += 1
+        return engine.rollout(population.contiguous(), s0, P, mode="exact", perms=perms[i].to(DEV), eps=eps[i].to(DEV))
+
+    seen = []
+    opt = hipets.CEMOptimizer(iters, 0.1, pop, lower.tolist(), upper.tolist(), 0.1, DEV, return_mean_elites=True, seed=0)
+    out = opt.optimize(engine_obj, x0=torch.zeros(H, act), noise=z, callback=lambda p_, v_, i_: seen.append((p_.clone(), v_.clone())))
+    K = int(opt.elite_num)
+    for i in range(iters):
+        population, values = seen[i]
+        assert torch.allclose(population.cpu(), rec[i]["population"], rtol=0, atol=1e-5)
+        v_ref = rec[i]["values"]
+        assert ((values.cpu() - v_ref).abs() <= 1e-4 * torch.clamp(v_ref.abs(), min=1.0)).all()  # T2
+        mine = set(values.cpu().topk(K).indices.tolist())
+        theirs = set(rec[i]["elite_idx"].tolist())
+        kth = v_ref.topk(K + 1).values
+        if (kth[K - 1] - kth[K]).abs() > 2e-4 * max(1.0, float(kth[K - 1].abs())):  # no tie at the elite boundary
+            assert mine == theirs, i  # T3
+    assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-4)  # T4: same plan, hence the same first action
