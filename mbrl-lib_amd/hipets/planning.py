@@ -472,6 +472,22 @@ class Optimizer:  # trajectory_opt.py:21-40
         raise NotImplementedError
 
 
+def _reference_noise(shape, clipped_normal: bool) -> torch.Tensor:
+    """The standard-normal draws of CEMOptimizer._sample_population on a CPU device, from torch's global generator:
+    ``randn`` for the clipped-normal branch (trajectory_opt.py:116-117), otherwise mbrl.util.math.truncated_normal_
+    (util/math.py:69-92): N(0, 1), entries outside [-2, 2] redrawn until none is left."""
+    if clipped_normal:
+        return torch.randn(shape)
+    t = torch.zeros(shape)
+    torch.nn.init.normal_(t, mean=0.0, std=1.0)
+    while True:
+        cond = torch.logical_or(t < -2.0, t > 2.0)
+        n = int(torch.sum(cond).item())
+        if n == 0:
+            return t
+        t[cond] = torch.normal(0.0, 1.0, size=(n,))
+
+
 class CEMOptimizer(Optimizer):
     """Cross-Entropy Method with device-side sampling and elite refit (trajectory_opt.py:43-188).
 
@@ -482,8 +498,14 @@ class CEMOptimizer(Optimizer):
     def __init__(self, num_iterations: int, elite_ratio: float, population_size: int,
                  lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]], alpha: float,
                  device: torch.device, return_mean_elites: bool = False, clipped_normal: bool = False,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, sampler: str = "philox"):
         super().__init__()
+        if sampler not in ("philox", "torch"):
+            raise ValueError("sampler must be 'philox' (device-side, default) or 'torch' (the reference's draws)")
+        # sampler='torch': the population noise is drawn exactly like the reference does on a CPU device (torch's GLOBAL
+        # generator, redraw-until-inside loop of mbrl.util.math.truncated_normal_, util/math.py:69-92), so that with the
+        # same torch.manual_seed an agent reproduces the reference's action selection (a parity aid: it synchronises)
+        self.sampler = sampler
         self.num_iterations = num_iterations
         self.elite_ratio = elite_ratio
         self.population_size = population_size
@@ -519,7 +541,7 @@ class CEMOptimizer(Optimizer):
                  callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
         x0 = x0.to(device=self.device, dtype=torch.float32).contiguous()
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and x0.ndim == 2) else None
+        fused = _fused_target(obj_fun) if (callback is None and x0.ndim == 2 and self.sampler == "philox") else None
         if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
             _prepare_fused(fused, [self.population_size])
             return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
@@ -533,6 +555,8 @@ class CEMOptimizer(Optimizer):
         noise = kwargs.get("noise")  # optional injected z per iteration (parity tests)
         for i in range(self.num_iterations):
             z = None if noise is None else noise[i].to(self.device, torch.float32).contiguous()
+            if z is None and self.sampler == "torch":
+                z = _reference_noise(tuple(population.shape), self._clipped_normal).to(self.device).contiguous()
             self.engine.cem_sample(p, mu, dispersion, self.lower_bound, self.upper_bound, population, z=z,
                                    seed=self.seed, stream_id=self.calls * self.num_iterations + i)
             values = obj_fun(population)
