@@ -576,8 +576,11 @@ class MPPIOptimizer(Optimizer):
 
     def __init__(self, num_iterations: int, population_size: int, gamma: float, sigma: float, beta: float,
                  lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]], device: torch.device,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, sampler: str = "philox"):
         super().__init__()
+        if sampler not in ("philox", "torch"):
+            raise ValueError("sampler must be 'philox' (device-side, default) or 'torch' (the reference's draws)")
+        self.sampler = sampler  # 'torch': noise like the reference (global generator, truncated_normal_, :262-271)
         self.planning_horizon = len(lower_bound)
         self.population_size = population_size
         self.action_dimension = len(lower_bound[0])
@@ -597,7 +600,7 @@ class MPPIOptimizer(Optimizer):
                  callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
         H, A, pop = self.planning_horizon, self.action_dimension, self.population_size
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("noise") is None) else None
+        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("noise") is None and self.sampler == "philox") else None
         if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
             _prepare_fused(fused, [pop])
             self.mean = self.mean.contiguous()
@@ -612,6 +615,8 @@ class MPPIOptimizer(Optimizer):
         noise = kwargs.get("noise")
         for k in range(self.refinements):
             z = None if noise is None else noise[k].to(self.device, torch.float32).contiguous()
+            if z is None and self.sampler == "torch":
+                z = _reference_noise((pop, H, A), False).to(self.device).contiguous()
             self.engine.mppi_sample(pop, H, A, self.beta, self.mean, past_action, self.lower_bound, self.upper_bound, population,
                                     z=z, seed=self.seed, stream_id=self.calls * self.refinements + k)
             values = obj_fun(population)

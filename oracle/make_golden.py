@@ -268,7 +268,7 @@ def gen_planet(name, latent, action, belief, hidden, pop, P, H, seed):
     print(f"planet_{name}: B={pop * P} returns[{ref.min():.3f},{ref.max():.3f}]  oracle==reference bitwise")
 
 
-def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2):
+def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2, optimizer="cem"):
     """The whole seam: the UNMODIFIED reference TrajectoryOptimizerAgent (CEM, truncated normal) planning through the
     reference ModelEnv on CPU under fixed seeds (torch.manual_seed for the sampler + randperms, a generator for eps);
     records the actions / plans of consecutive act() calls (the second uses the shifted warm start)."""
@@ -278,9 +278,13 @@ def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2):
     om = po.make_synthetic_model(obs, act, **mkw)
     gen = torch.Generator().manual_seed(21)
     me, _, _ = build_reference_model_env(om, obs, act, generator=gen)
-    cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.CEMOptimizer", num_iterations=iters, elite_ratio=0.1, population_size=pop,
-                                          alpha=0.1, device="cpu", lower_bound="???", upper_bound="???", return_mean_elites=True,
-                                          clipped_normal=False))
+    if optimizer == "mppi":  # conf/action_optimizer/mppi.yaml with overrides/pets_mppi_halfcheetah.yaml:19-24
+        cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.MPPIOptimizer", num_iterations=iters, population_size=pop, gamma=0.9,
+                                              sigma=1.0, beta=0.9, device="cpu", lower_bound="???", upper_bound="???"))
+    else:
+        cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.CEMOptimizer", num_iterations=iters, elite_ratio=0.1,
+                                              population_size=pop, alpha=0.1, device="cpu", lower_bound="???", upper_bound="???",
+                                              return_mean_elites=True, clipped_normal=False))
     agent = mbrl.planning.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H, replan_freq=1)
     agent.set_trajectory_eval_fn(lambda s, a: me.evaluate_action_sequences(a, initial_state=s, num_particles=P))
     rng = np.random.default_rng(8)
@@ -293,7 +297,7 @@ def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2):
         plans.append(agent.optimizer.previous_solution.numpy().copy())  # shifted plan kept for the next call
     arrays = dict(observations=observations, actions=np.stack(actions), shifted_plans=np.stack(plans))
     save_case(os.path.join(OUT, f"agent_{name}.npz"), om, dict(kind="agent", obs_dim=obs, act_dim=act, pop=pop, P=P, H=H, iters=iters,
-                                                              torch_seed=4321, generator_seed=21), arrays)
+                                                              torch_seed=4321, generator_seed=21, optimizer=optimizer), arrays)
     print(f"agent_{name}: actions {np.stack(actions).round(4).tolist()}")
 
 
@@ -308,6 +312,7 @@ def main():
     gen_mppi()
     gen_icem()
     gen_agent_act("cem_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=20, no_delta_list=[0]), pop=60, P=5, H=8, iters=4)
+    gen_agent_act("mppi_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=22), pop=50, P=5, H=7, iters=3, optimizer="mppi")
     gen_planet("cheetah_shape", 30, 6, 200, 200, pop=40, P=1, H=12, seed=1)   # conf/dynamics_model/planet.yaml sizes
     gen_planet("small_particles", 10, 3, 40, 24, pop=11, P=3, H=5, seed=2)
 

@@ -529,16 +529,21 @@ def test_full_plan_reference_order_same_elites_and_action(engine):
     assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-4)  # T4: same plan, hence the same first action
 
 
-def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds():
+@pytest.mark.parametrize("case", ["cem_two_steps", "mppi_two_steps"])
+def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
     """North star, end to end: `TrajectoryOptimizerAgent.act` with the same torch seeds as the unmodified reference agent
     (golden recorded from mbrl.planning.TrajectoryOptimizerAgent + mbrl.models.ModelEnv on CPU, oracle/make_golden.py)
     selects the same actions.  sampler='torch' + mode='exact' consume torch's generators in the reference's order:
     truncated-normal population noise and per-step randperms from the global generator, eps from ModelEnv's."""
-    om, meta, a = load_case(os.path.join(GOLDEN, "agent_cem_two_steps.npz"))
+    om, meta, a = load_case(os.path.join(GOLDEN, f"agent_{case}.npz"))
     obs, act, H, P = meta["obs_dim"], meta["act_dim"], meta["H"], meta["P"]
     fn = hipets.make_eval_fn(to_spec(om, obs, act), P, mode="exact", rng=torch.Generator().manual_seed(meta["generator_seed"]))
-    cfg = dict(_target_="hipets.CEMOptimizer", num_iterations=meta["iters"], elite_ratio=0.1, population_size=meta["pop"], alpha=0.1,
-               device=DEV, lower_bound="???", upper_bound="???", return_mean_elites=True, clipped_normal=False, sampler="torch")
+    if meta.get("optimizer", "cem") == "mppi":
+        cfg = dict(_target_="hipets.MPPIOptimizer", num_iterations=meta["iters"], population_size=meta["pop"], gamma=0.9, sigma=1.0,
+                   beta=0.9, device=DEV, lower_bound="???", upper_bound="???", sampler="torch")
+    else:
+        cfg = dict(_target_="hipets.CEMOptimizer", num_iterations=meta["iters"], elite_ratio=0.1, population_size=meta["pop"], alpha=0.1,
+                   device=DEV, lower_bound="???", upper_bound="???", return_mean_elites=True, clipped_normal=False, sampler="torch")
     agent = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H, replan_freq=1)
     agent.set_trajectory_eval_fn(fn)
     torch.manual_seed(meta["torch_seed"])
