@@ -638,8 +638,14 @@ class ICEMOptimizer(Optimizer):
     def __init__(self, num_iterations: int, elite_ratio: float, population_size: int, population_decay_factor: float,
                  colored_noise_exponent: float, lower_bound: Sequence[Sequence[float]], upper_bound: Sequence[Sequence[float]],
                  keep_elite_frac: float, alpha: float, device: torch.device, return_mean_elites: bool = False,
-                 population_size_module: Optional[int] = None, seed: Optional[int] = None):
+                 population_size_module: Optional[int] = None, seed: Optional[int] = None, sampler: str = "philox"):
         super().__init__()
+        if sampler not in ("philox", "torch"):
+            raise ValueError("sampler must be 'philox' (device-side, default) or 'torch' (the reference's draws)")
+        # 'torch': every draw of an iteration comes from torch's global CPU generator in the reference's order -- the two
+        # spectrum normals of powerlaw_psd_gaussian (util/math.py:372-377), randperm(elite_num) for the kept elites
+        # (trajectory_opt.py:446-448), the tail-action normal of the shifted elites (:451-457)
+        self.sampler = sampler
         self.num_iterations = num_iterations
         self.elite_ratio = elite_ratio
         self.population_size = population_size
@@ -681,7 +687,7 @@ class ICEMOptimizer(Optimizer):
         H, A = x0.shape
         K, keep = int(self.elite_num), int(self.keep_elite_size)
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("inject") is None) else None
+        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("inject") is None and self.sampler == "philox") else None
         if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
             sizes = []
             for i in range(self.num_iterations):
@@ -711,6 +717,13 @@ class ICEMOptimizer(Optimizer):
         for i in range(self.num_iterations):
             n = self._iteration_size(i)
             inj = inject[i] if inject is not None else {}
+            if inject is None and self.sampler == "torch":
+                F = H // 2 + 1
+                inj = {"normals": torch.stack([torch.empty(n, A, F).normal_(0.0, 1.0), torch.empty(n, A, F).normal_(0.0, 1.0)])}
+                if self.elite is not None:
+                    inj["keep_perm"] = torch.randperm(K)
+                    if i == 0:
+                        inj["end_noise"] = torch.empty(keep, A).normal_(0.0, 1.0)
             sid = (self.calls * self.num_iterations + i) * 4
             extra = 0
             if self.elite is not None:

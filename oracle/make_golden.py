@@ -278,7 +278,12 @@ def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2, optimizer="c
     om = po.make_synthetic_model(obs, act, **mkw)
     gen = torch.Generator().manual_seed(21)
     me, _, _ = build_reference_model_env(om, obs, act, generator=gen)
-    if optimizer == "mppi":  # conf/action_optimizer/mppi.yaml with overrides/pets_mppi_halfcheetah.yaml:19-24
+    if optimizer == "icem":  # conf/action_optimizer/icem.yaml with overrides/pets_icem_cartpole.yaml:16-23
+        cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.ICEMOptimizer", num_iterations=iters, elite_ratio=0.1,
+                                              population_size=pop, population_decay_factor=1.3, colored_noise_exponent=2.0,
+                                              keep_elite_frac=0.3, alpha=0.1, device="cpu", lower_bound="???", upper_bound="???",
+                                              return_mean_elites=True, population_size_module=5))
+    elif optimizer == "mppi":  # conf/action_optimizer/mppi.yaml with overrides/pets_mppi_halfcheetah.yaml:19-24
         cfg = omegaconf.OmegaConf.create(dict(_target_="mbrl.planning.MPPIOptimizer", num_iterations=iters, population_size=pop, gamma=0.9,
                                               sigma=1.0, beta=0.9, device="cpu", lower_bound="???", upper_bound="???"))
     else:
@@ -313,6 +318,7 @@ def main():
     gen_icem()
     gen_agent_act("cem_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=20, no_delta_list=[0]), pop=60, P=5, H=8, iters=4)
     gen_agent_act("mppi_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=22), pop=50, P=5, H=7, iters=3, optimizer="mppi")
+    gen_agent_act("icem_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=23), pop=60, P=5, H=8, iters=3, optimizer="icem")
     gen_planet("cheetah_shape", 30, 6, 200, 200, pop=40, P=1, H=12, seed=1)   # conf/dynamics_model/planet.yaml sizes
     gen_planet("small_particles", 10, 3, 40, 24, pop=11, P=3, H=5, seed=2)
 

@@ -529,7 +529,7 @@ def test_full_plan_reference_order_same_elites_and_action(engine):
     assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-4)  # T4: same plan, hence the same first action
 
 
-@pytest.mark.parametrize("case", ["cem_two_steps", "mppi_two_steps"])
+@pytest.mark.parametrize("case", ["cem_two_steps", "mppi_two_steps", "icem_two_steps"])
 def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
     """North star, end to end: `TrajectoryOptimizerAgent.act` with the same torch seeds as the unmodified reference agent
     (golden recorded from mbrl.planning.TrajectoryOptimizerAgent + mbrl.models.ModelEnv on CPU, oracle/make_golden.py)
@@ -538,7 +538,11 @@ def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
     om, meta, a = load_case(os.path.join(GOLDEN, f"agent_{case}.npz"))
     obs, act, H, P = meta["obs_dim"], meta["act_dim"], meta["H"], meta["P"]
     fn = hipets.make_eval_fn(to_spec(om, obs, act), P, mode="exact", rng=torch.Generator().manual_seed(meta["generator_seed"]))
-    if meta.get("optimizer", "cem") == "mppi":
+    if meta.get("optimizer", "cem") == "icem":
+        cfg = dict(_target_="hipets.ICEMOptimizer", num_iterations=meta["iters"], elite_ratio=0.1, population_size=meta["pop"],
+                   population_decay_factor=1.3, colored_noise_exponent=2.0, keep_elite_frac=0.3, alpha=0.1, device=DEV,
+                   lower_bound="???", upper_bound="???", return_mean_elites=True, population_size_module=5, sampler="torch")
+    elif meta.get("optimizer", "cem") == "mppi":
         cfg = dict(_target_="hipets.MPPIOptimizer", num_iterations=meta["iters"], population_size=meta["pop"], gamma=0.9, sigma=1.0,
                    beta=0.9, device=DEV, lower_bound="???", upper_bound="???", sampler="torch")
     else:
