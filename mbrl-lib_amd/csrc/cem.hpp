@@ -72,7 +72,7 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
 // dimensions d of the [H,A] plan and reduces the K elites in f64.
 constexpr int kRefitThreads = 1024;
 constexpr int kMaxPop = 8192;
-constexpr int kRankSortMax = 2048;  // up to here the O(n^2 / threads) rank count beats the bitonic network
+constexpr int kRankSortMax = 512;   // up to here the O(n^2 / threads) rank count beats the bitonic network
 
 __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* values, const float* population, float* mu,
                                                                  float* disp, float* best_value, float* best_solution,
