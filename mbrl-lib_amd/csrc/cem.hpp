@@ -67,13 +67,17 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
     population[i] = x;
 }
 
-// NaN filter + top-k + refit + best-so-far in ONE workgroup (pop <= kMaxPop): values are sorted with
-// a bitonic network in LDS (descending, ties broken by lower index), then each thread owns
-// dimensions d of the [H,A] plan and reduces the K elites in f64.
+// NaN filter + top-k + refit + best-so-far in ONE workgroup (pop <= kMaxPop): the K best values are found in LDS
+// (descending, ties broken by lower index: rank counting for small populations, a radix select + a sort of the elites for
+// larger ones, a full bitonic network when K > kSelectMaxK), then threads share the dimensions d of the [H,A] plan and
+// reduce the K elites in f64.
 constexpr int kRefitThreads = 1024;
 constexpr int kMaxPop = 8192;
-constexpr int kRankSortMax = 1400;  // populations up to here: the O(n^2 / threads) rank count beats the bitonic network
-                                    // (measured 8.6 / 24 / 73 us vs 16 / 45 / 53 us at pop 500 / 1036 / 2000)
+constexpr int kRefitScratchBytes = 12288;  // LDS behind the key / index arrays: f64 partial sums, or the selection's work space
+constexpr int kSelectMaxK = 1024;          // radix top-k below handles elite counts up to here (else: full bitonic sort)
+constexpr int kRankSortMax = 640;   // populations up to here: O(n^2 / threads) rank counting (14 us at pop 500); above, the
+                                    // radix select (22 / 36 / 64 / 120 us at pop 1036 / 2000 / 4000 / 8000; the bitonic
+                                    // network it replaced took 45 / 52 / 105 us at 1036 / 2000 / 4000)
 
 __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p, float* values, const float* population, float* mu,
                                                                  float* disp, float* best_value, float* best_solution,
@@ -120,13 +124,94 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         }
         __syncthreads();
         // scatter: sorted position -> element; ranks are a permutation of 0..pop-1
-        int* pos = reinterpret_cast<int*>(smem + (size_t)n2 * 8);  // reuses the refit scratch (free until the barrier below)
+        int* pos = reinterpret_cast<int*>(smem + (size_t)n2 * 8);  // the scratch region (free until the barrier below)
         for (int i = tid; i < p.pop; i += kRefitThreads) pos[idx[i]] = i;
         __syncthreads();
         float top_key = key[pos[0]];
         __syncthreads();
         for (int i = tid; i < p.pop; i += kRefitThreads) idx[i] = pos[i];
         if (tid == 0) key[0] = top_key;  // key[] is only consulted at position 0 from here on
+        __syncthreads();
+    } else if (p.K <= kSelectMaxK) {
+        // larger populations (sharded multi-GPU plans, iCEM's first iterations): only the K best are needed, so select
+        // instead of sorting.  Four 8-bit radix passes over order-preserving integer keys find the K-th largest key T
+        // (LDS histogram + a 256-bin scan per pass); the elites are {key > T} plus the lowest-index elements with
+        // key == T; they are then ordered among themselves by rank counting (K^2 / threads compares).
+        int* hist = reinterpret_cast<int*>(smem + (size_t)n2 * 8);  // [256]
+        int* ctl = hist + 256;                                      // prefix, mask, still needed, elite counter
+        int* elist = ctl + 8;                                       // [K] element ids, unordered
+        float* ekey = reinterpret_cast<float*>(elist + kSelectMaxK);  // [K] their keys
+        auto okey = [](float v) {  // monotone increasing in v
+            const unsigned u = __float_as_uint(v + 0.0f);  // -0.0 -> +0.0: equal floats get equal keys
+            return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        };
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = p.K; ctl[3] = 0; }
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int b = tid; b < 256; b += kRefitThreads) hist[b] = 0;
+            __syncthreads();
+            const unsigned prefix = (unsigned)ctl[0], mask = (unsigned)ctl[1];
+            for (int i = tid; i < p.pop; i += kRefitThreads) {
+                const unsigned u = okey(key[i]);
+                if ((u & mask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {  // wave 0: the bin holding the (still needed)-th largest candidate.  Lane l owns bins 4l .. 4l+3.
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int mine = h0 + h1 + h2 + h3;
+                int above = mine;  // inclusive suffix sum over lanes (bins above and including mine)
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_down(above, d, 64);
+                    if (tid + d < 64) above += o;
+                }
+                const int need = ctl[2];
+                const int higher = above - mine;  // candidates in bins of higher lanes
+                if (higher < need && need <= above) {  // exactly one lane: the K-th largest falls into my four bins
+                    int n = need - higher, b = 4 * tid + 3;
+                    if (n > h3) { n -= h3; b = 4 * tid + 2;
+                        if (n > h2) { n -= h2; b = 4 * tid + 1;
+                            if (n > h1) { n -= h1; b = 4 * tid; } } }
+                    ctl[0] = (int)(prefix | ((unsigned)b << (8 * pass)));
+                    ctl[1] = (int)(mask | (255u << (8 * pass)));
+                    ctl[2] = n;  // how many elements of this bin (finally: with key == T) are elites
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned T = (unsigned)ctl[0];
+        const int need_eq = ctl[2];
+        const bool all_eq = hist[T & 255u] == need_eq;  // the last pass's bin of T counted the elements with key == T
+        for (int i = tid; i < p.pop; i += kRefitThreads) {
+            const unsigned u = okey(key[i]);
+            bool elite = u > T || (u == T && all_eq);
+            if (u == T && !all_eq) {  // more ties at the threshold than places: the lowest indices win (as in the full sorts)
+                int before = 0;
+                for (int j = 0; j < i; ++j) before += okey(key[j]) == T;
+                elite = before < need_eq;
+            }
+            if (elite) {
+                const int slot = atomicAdd(&ctl[3], 1);
+                elist[slot] = i;
+                ekey[slot] = key[i];
+            }
+        }
+        __syncthreads();
+        // order the K elites: position = #{elites before me}
+        int my_pos = -1, my_id = 0;
+        float my_key = 0.f;
+        if (tid < p.K) {
+            my_id = elist[tid];
+            my_key = ekey[tid];
+            int rank = 0;
+            for (int f = 0; f < p.K; ++f) {
+                const float kf = ekey[f];
+                rank += (kf > my_key) || (kf == my_key && elist[f] < my_id);
+            }
+            my_pos = rank;
+        }
+        __syncthreads();
+        if (my_pos >= 0) idx[my_pos] = my_id;
+        if (my_pos == 0) key[0] = my_key;  // key[] is only consulted at position 0 from here on
         __syncthreads();
     } else
     for (int k = 2; k <= n2; k <<= 1) {

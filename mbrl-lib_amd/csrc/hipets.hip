@@ -646,7 +646,7 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
     const CemDev c = make_cem(p);
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, reinterpret_cast<hipStream_t>(stream), c,
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, elite_idx);
     HCHECK(hipGetLastError());
     return 0;
@@ -761,7 +761,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
         if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream,
                          sched ? sched + (size_t)i * sched_stride : nullptr))
             return 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, st, c, e->values.as<float>(),
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), (int*)nullptr);
         HCHECK(hipGetLastError());
@@ -891,7 +891,7 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         if (check_cem(&cp)) return 1;
         int n2 = 1;
         while (n2 < rows) n2 <<= 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitThreads * 8, st, make_cem(&cp), e->values.as<float>(), popbuf,
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp), e->values.as<float>(), popbuf,
                            e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(), e->best_solution.as<float>(),
                            e->elite_idx.as<int>());
         HCHECK(hipGetLastError());

@@ -555,3 +555,34 @@ def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
         action = agent.act(a["observations"][t].numpy())
         assert np.allclose(action, a["actions"][t].numpy(), rtol=0, atol=1e-4), t
         assert np.allclose(agent.optimizer.previous_solution.cpu().numpy(), a["shifted_plans"][t].numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("pop,K,ties", [(4000, 400, False), (2000, 200, True), (8192, 820, False), (1500, 1, True), (3000, 1500, False)])
+def test_refit_large_populations_select_path(engine, pop, K, ties):
+    """Populations of sharded multi-GPU plans (pop 500 x 8 ranks) and beyond: the top-k is a radix select + a sort of the
+    elites (a full bitonic sort when K > 1024).  Elite indices in order (ties -> lower index first, NaN -> -1e-10 first),
+    refit statistics and best-so-far against torch / f64."""
+    H, A = 5, 3
+    g = torch.Generator().manual_seed(pop)
+    values = torch.randn(pop, generator=g)
+    if ties:
+        values = (values * 4).round() / 4  # many exact duplicates, also across the elite threshold
+        values[5] = float("nan"); values[77] = float("nan")
+    population = torch.randn(pop, H, A, generator=g)
+    p = hipets.Engine.cem_params(pop, H, A, 1, K, 0.1, True, False, True)
+    mu, disp = torch.zeros(H, A, device=DEV), torch.ones(H, A, device=DEV)
+    best_v, best_s = torch.full((1,), -float("inf"), device=DEV), torch.zeros(H, A, device=DEV)
+    eidx = torch.empty(K, dtype=torch.int32, device=DEV)
+    vals_dev = values.to(DEV)
+    engine.cem_refit(p, vals_dev, population.to(DEV).contiguous(), mu, disp, best_v, best_s, eidx)
+    v = values.clone()
+    v[v.isnan()] = -1e-10
+    order = sorted(range(pop), key=lambda i: (-float(v[i]), i))[:K]  # value descending, index ascending
+    assert eidx.cpu().tolist() == order
+    elite = population[order].double()
+    new_mu = elite.mean(0)
+    assert torch.allclose(mu.cpu().double(), 0.9 * new_mu, atol=1e-6)
+    if K > 1:
+        assert torch.allclose(disp.cpu().double(), 0.1 + 0.9 * elite.var(0, unbiased=True), atol=1e-5)
+    assert float(best_v) == float(v[order[0]]) and torch.equal(best_s.cpu(), population[order[0]])
+    assert torch.equal(vals_dev.cpu(), v)  # NaNs replaced in place like the reference
