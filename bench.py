@@ -274,6 +274,25 @@ def main():
         exact_sem = {"workload": "configs[1] with mode='exact_device': reference TS1 semantics (global randperm per step), device RNG",
                      "value": nx * ITERS * POP * PARTICLES * HORIZON / ex, "unit": "candidate-steps/s", "ms_per_plan": 1e3 * ex / nx}
 
+    # extra (N = 1 only): the whole drop-in call, TrajectoryOptimizerAgent.act(obs) -> np.ndarray[A]: observation from host
+    # memory, plan on the device, ONE D2H of the plan, warm-start shift (what a control loop pays per environment step)
+    agent_act = None
+    if world == 1 and not args.no_batched:
+        cfg = dict(_target_="hipets.CEMOptimizer", num_iterations=ITERS, elite_ratio=ELITE_RATIO, population_size=POP, alpha=ALPHA,
+                   device=device, lower_bound="???", upper_bound="???", return_mean_elites=True, seed=0)
+        agent = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * ACT, [1.0] * ACT, planning_horizon=HORIZON)
+        agent.set_trajectory_eval_fn(eval_fn)
+        for _ in range(3):
+            agent.act(s0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        na = max(5, args.steps // 2)
+        for _ in range(na):
+            agent.act(s0)
+        ea = time.perf_counter() - t0  # act() returns host data: it is synchronous by construction
+        agent_act = {"workload": "hipets.TrajectoryOptimizerAgent.act(obs) on configs[1], host observation in, host action out",
+                     "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea}
+
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     value = args.steps * cand_steps_per_plan / elapsed
     flops_cs = spec.flops_per_candidate_step()
@@ -312,6 +331,8 @@ def main():
         out["batched_planning"] = batched
     if exact_sem is not None:
         out["exact_semantics"] = exact_sem
+    if agent_act is not None:
+        out["agent_act"] = agent_act
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
