@@ -254,6 +254,21 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
                      float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t num_particles,
                      uint64_t seed, uint64_t plan_id, float* out, void* stream);
 
+/* ---- multi-GPU: population sharding with ONE all-gather of returns per iteration --------------------- */
+/* The library talks to RCCL itself (librccl is loaded on first use, no link-time dependency): rank 0 makes an id, the
+ * host broadcasts its HIPETS_COMM_ID_BYTES bytes by any means (MPI, torch.distributed, a file), every rank joins.        */
+#define HIPETS_COMM_ID_BYTES 128
+int hipets_comm_unique_id(void* id_out);
+int hipets_comm_init(hipets_engine* e, const void* unique_id, int32_t rank, int32_t world_size);
+int hipets_comm_destroy(hipets_engine* e);
+/* hipets_plan_cem over all ranks of the communicator as one device-side loop per rank: every rank passes IDENTICAL
+ * arguments; the population is sampled identically everywhere (counter-based RNG), rank r rolls out candidates
+ * [r * pop / world ...) (first pop % world ranks hold one more), one ncclAllGather of the per-candidate returns per
+ * iteration over xGMI, then the same refit on the same data everywhere (bit-identical mu / dispersion, no broadcast).
+ * With world_size == 1 it equals hipets_plan_cem.                                                                          */
+int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
+                            const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id, float* out, void* stream);
+
 /* ---- PlaNet latent planner (mbrl/models/planet.py) ----------------------------------- */
 /* The tensors PlaNetModel.sample reads (planet.py:531-581), DEVICE f32 in nn.Linear layout: weights [out, in]
  * row-major, biases [out].  The library packs private copies; call again after every model update.            */

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -76,6 +78,10 @@ struct hipets_engine {
     DevBuf s0, state, totals, term, schedule, plan_schedule;
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
+    // RCCL communicator (lazy-loaded librccl)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf shard_values, gathered;
     // PlaNet latent model
     bool has_planet = false;
     PlanetDev pd{};
@@ -190,6 +196,59 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     return 0;
 }
 
+// ---- RCCL through dlopen: no link-time dependency, and inside a PyTorch process the already loaded librccl is reused ----
+struct RcclId { char internal[HIPETS_COMM_ID_BYTES]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId /* ncclUniqueId by value */, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail("cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclId, int)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(lib, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) return fail("librccl lacks an expected symbol");
+    g_rccl.lib = lib;
+    return 0;
+}
+#define NCHECK(x)                                                                                        \
+    do {                                                                                                 \
+        const int r_ = (x);                                                                              \
+        if (r_ != 0) return fail("RCCL error %d (%s) at %s:%d", r_, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
+    } while (0)
+
+// candidates of rank r when pop candidates are dealt to `world` ranks (first pop % world ranks hold one more)
+inline void shard_bounds(int pop, int world, int r, int* lo, int* hi) {
+    const int base = pop / world, extra = pop % world;
+    *lo = r * base + std::min(r, extra);
+    *hi = *lo + base + (r < extra ? 1 : 0);
+}
+
+// gathered [world, width] (rank r's shard in row r, padded) -> values [pop]
+__global__ void unpad_shards_kernel(const float* gathered, float* values, int pop, int world, int width) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pop) return;
+    const int base = pop / world, extra = pop % world;
+    const int split = extra * (base + 1);  // candidates held by the ranks with one more
+    const int r = i < split ? i / (base + 1) : extra + (i - split) / base;
+    const int lo = r * base + min(r, extra);
+    values[i] = gathered[(size_t)r * width + (i - lo)];
+}
+
 CemDev make_cem(const hipets_cem_params* p, int n_env = 1) {
     CemDev c{};
     c.n_env = n_env;
@@ -251,9 +310,10 @@ int hipets_create(int device, hipets_engine** out) {
 void hipets_destroy(hipets_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
     for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
                       &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->mu, &e->disp, &e->population, &e->values,
-                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops})
+                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -1014,6 +1074,103 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     HCHECK(hipGetLastError());
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_comm_unique_id(void* id_out) {
+    if (!id_out) return fail("null argument");
+    if (rccl_load()) return 1;
+    NCHECK(g_rccl.GetUniqueId(id_out));
+    return 0;
+}
+
+int hipets_comm_init(hipets_engine* e, const void* unique_id, int32_t rank, int32_t world) {
+    if (!e || !unique_id) return fail("null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad rank %d / world_size %d", rank, world);
+    if (rccl_load()) return 1;
+    HCHECK(hipSetDevice(e->device));
+    if (e->comm) {
+        NCHECK(g_rccl.CommDestroy(e->comm));
+        e->comm = nullptr;
+    }
+    RcclId id;
+    std::memcpy(id.internal, unique_id, HIPETS_COMM_ID_BYTES);
+    NCHECK(g_rccl.CommInitRank(&e->comm, world, id, rank));
+    e->comm_rank = rank;
+    e->comm_world = world;
+    return 0;
+}
+
+int hipets_comm_destroy(hipets_engine* e) {
+    if (!e) return fail("null engine");
+    if (e->comm) {
+        HCHECK(hipSetDevice(e->device));
+        NCHECK(g_rccl.CommDestroy(e->comm));
+        e->comm = nullptr;
+    }
+    e->comm_rank = 0;
+    e->comm_world = 1;
+    return 0;
+}
+
+int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
+                            const float* s0, int32_t P, uint64_t seed, uint64_t plan_id, float* out, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
+    if (!e->comm) return fail("no communicator (call hipets_comm_init)");
+    if (check_cem(p)) return 1;
+    if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
+    if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
+    const int world = e->comm_world, rank = e->comm_rank;
+    if (p->population_size < world) return fail("population_size %d < world_size %d", p->population_size, world);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const CemDev c = make_cem(p, 1);
+    int lo, hi;
+    shard_bounds(c.pop, world, rank, &lo, &hi);
+    const int local = hi - lo, width = (c.pop + world - 1) / world;
+    const size_t nd = (size_t)c.D;
+    if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
+        e->population.ensure((size_t)c.pop * nd * 4) || e->values.ensure((size_t)c.pop * 4) || e->shard_values.ensure((size_t)width * 4) ||
+        e->gathered.ensure((size_t)world * width * 4))
+        return 1;
+    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
+                       e->disp.as<float>(), e->best_value.as<float>());
+    HCHECK(hipGetLastError());
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
+    HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
+    hipets_rollout_opts ro{};
+    ro.mode = HIPETS_MODE_FAST;
+    ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_cem)
+    int n2 = 1;
+    while (n2 < c.pop) n2 <<= 1;
+    const int* sched = nullptr;
+    size_t sched_stride = 0;
+    if (plan_prologue(e, s0, 1, local, P, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st, &sched, &sched_stride))
+        return 1;
+    for (int i = 0; i < p->num_iterations; ++i) {
+        const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
+        const long long n = (long long)c.pop * c.D;
+        hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
+                           lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
+                           e->population.as<float>());  // identical on every rank: same seed, same counters
+        HCHECK(hipGetLastError());
+        ro.stream_id = sid;
+        float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
+        if (rollout_impl(e, e->population.as<float>() + (size_t)lo * nd, nullptr, local, c.H, P, &ro, shard_out, stream,
+                         sched ? sched + (size_t)i * sched_stride : nullptr))
+            return 1;
+        if (world > 1) {
+            NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
+            hipLaunchKernelGGL(unpad_shards_kernel, dim3((c.pop + 255) / 256), dim3(256), 0, st, e->gathered.as<float>(), e->values.as<float>(),
+                               c.pop, world, width);
+            HCHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+                           e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                           e->best_solution.as<float>(), (int*)nullptr);
+        HCHECK(hipGetLastError());
+    }
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -109,6 +109,10 @@ SYMBOLS = {
                                    C.c_uint64, C.c_uint64, _P]),
     "hipets_plan_icem": (C.c_int, [_P, C.POINTER(IcemParams), _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64, C.c_uint64,
                                    _P, _P]),
+    "hipets_comm_unique_id": (C.c_int, [_P]),
+    "hipets_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "hipets_comm_destroy": (C.c_int, [_P]),
+    "hipets_plan_cem_sharded": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_planet_set_model": (C.c_int, [_P, C.POINTER(PlanetDesc), _P]),
     "hipets_planet_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PlanetOpts), _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
@@ -116,6 +120,9 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+COMM_ID_BYTES = 128
 
 
 class HipetsError(RuntimeError):

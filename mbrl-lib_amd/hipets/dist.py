@@ -76,3 +76,14 @@ class ShardedEvalFn:
 
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_engine_comm(engine, group=None):
+    """Give ``engine`` its own RCCL communicator over the ranks of ``group`` (hipets_comm_init): rank 0 creates the id,
+    torch.distributed only carries its 128 bytes.  Afterwards ``Engine.plan_cem_sharded`` runs the whole sharded plan as one
+    device-side loop per rank (no per-iteration host work)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0], rank, world)
+    return engine

@@ -67,6 +67,7 @@ class Engine:
         self._h = h
         self.spec: Optional[ModelSpec] = None
         self.planet_spec = None
+        self.comm_world, self.comm_rank = 1, 0
         self._keep = []  # device tensors that must outlive async set_model work
 
     def close(self):
@@ -438,6 +439,44 @@ class Engine:
                                                   int(bool(has_elite)), _ptr(keep_idx) if keep_idx is not None else None,
                                                   s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
                                                   int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
+    # ---- in-library RCCL communicator (population-sharded fused plans) -----------------------------
+    def comm_unique_id(self) -> bytes:
+        """A fresh communicator id (rank 0 makes it, the host broadcasts the bytes to the other ranks)."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(self._lib.hipets_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.COMM_ID_BYTES} bytes")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hipets_comm_init(self._h, C.c_char_p(unique_id), int(rank), int(world_size)))
+        self.comm_world, self.comm_rank = int(world_size), int(rank)
+
+    def comm_destroy(self):
+        _lib.check(self._lib.hipets_comm_destroy(self._h))
+        self.comm_world, self.comm_rank = 1, 0
+
+    def plan_cem_sharded(self, p: CemParams, x0, lower, upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """hipets_plan_cem over all ranks of the communicator (identical arguments on every rank)."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_cem_sharded(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper),
+                                                         s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                         int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
         return out
 
     # ---- PlaNet latent planner (SURVEY.md 8f row 4) -----------------------------------------------

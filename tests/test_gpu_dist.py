@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+import hipets  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -56,3 +58,34 @@ def test_two_ranks_one_gpu_sharded_cem(tmp_path):
     for pa, pb, va, vb in zip(a["pops"], b["pops"], a["vals"], b["vals"]):
         assert torch.equal(pa, pb)  # replicated sampling
         assert torch.equal(va, vb) and va.shape[0] == 101  # every rank holds all gathered returns
+
+
+DEV = "cuda:0"
+
+
+def test_in_library_rccl_communicator_world_one_equals_fused_plan(engine):
+    """hipets_comm_unique_id / hipets_comm_init / hipets_plan_cem_sharded with a one-rank communicator (all a 1-GPU box can
+    hold): librccl is loaded lazily, the communicator comes up, and the sharded plan is the fused plan bit for bit."""
+    import numpy as np
+
+    from conftest import to_spec
+    from oracle import pets_oracle as po
+
+    obs, act, H, P, pop = 17, 6, 8, 5, 60
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=2)
+    engine.set_model(to_spec(om, obs, act))
+    p = hipets.Engine.cem_params(pop, H, act, 3, 6, 0.1, True, False, True)
+    lower, upper = -torch.ones(H, act, device=DEV), torch.ones(H, act, device=DEV)
+    x0 = torch.zeros(H, act, device=DEV)
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+    with pytest.raises(hipets.HipetsError, match="no communicator"):
+        engine.plan_cem_sharded(p, x0, lower, upper, s0, P, seed=3, plan_id=1)
+    uid = engine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(uid, 0, 1)
+    try:
+        a = engine.plan_cem_sharded(p, x0, lower, upper, s0, P, seed=3, plan_id=1)
+        b = engine.plan_cem(p, x0, lower, upper, s0, P, seed=3, plan_id=1)
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    finally:
+        engine.comm_destroy()
