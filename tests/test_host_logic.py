@@ -178,3 +178,23 @@ def test_member_slots_pads_unbalanced_member_maps():
         assert torch.equal(torch.cat(seen).sort().values, torch.arange(B))
     tight, rpm2 = member_slots(members[:1], M, "cpu")
     assert rpm2 == int(torch.bincount(members[0], minlength=M).max()) and tight.shape[1] == M * rpm2
+
+
+def test_reference_noise_consumes_the_global_generator_like_the_reference():
+    """sampler='torch': the product's draw routine == mbrl.util.math.truncated_normal_ (util/math.py:69-92, restated in the
+    oracle and pinned bitwise against the reference) on the same torch.manual_seed; the clipped-normal branch is randn."""
+    from hipets.planning import _reference_noise
+    from oracle import pets_oracle as po
+
+    torch.manual_seed(123)
+    a = _reference_noise((40, 6, 3), clipped_normal=False)
+    after_a = torch.rand(1)
+    torch.manual_seed(123)
+    b = po.truncated_normal_(torch.zeros(40, 6, 3))
+    after_b = torch.rand(1)
+    assert torch.equal(a, b) and torch.equal(after_a, after_b)  # same values AND same generator state afterwards
+    assert a.abs().max() <= 2.0
+    torch.manual_seed(5)
+    c = _reference_noise((7, 2), clipped_normal=True)
+    torch.manual_seed(5)
+    assert torch.equal(c, torch.randn(7, 2))
