@@ -17,7 +17,12 @@
  *     HOST are read during the call only.  The library retains no caller pointer past a call,
  *     except hipets_set_model which copies weights into its own packed layout.
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
- *     enqueued asynchronously on it; there is no hidden device synchronisation.
+ *     enqueued asynchronously on it.  Two entry points synchronise `stream` before returning, because
+ *     they read caller-owned DEVICE tensors that may be freed right after the call: hipets_set_model
+ *     and hipets_planet_set_model.  hipets_timing_read waits for the events it reports.  Nothing else
+ *     synchronises.
+ *   - HOST arrays (observations, descriptors) are consumed before the call returns (small pageable
+ *     hipMemcpyAsync H2D copies are staged by the runtime at enqueue time), so temporaries are fine.
  *   - one engine per device; an engine is not thread-safe (the reference is single-threaded).
  */
 #ifndef HIPETS_H
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HIPETS_ABI_VERSION 1
+#define HIPETS_ABI_VERSION 2
 #define HIPETS_MAX_LAYERS 8
 
 typedef struct hipets_engine hipets_engine;
@@ -55,8 +60,13 @@ enum { HIPETS_NORM_NONE = 0, HIPETS_NORM_F32 = 1, HIPETS_NORM_F64 = 2 };
  * (basic_ensemble.py:122-129, 255-260), any batch size, no elites (:262-266), per-member logvar bounds. */
 enum { HIPETS_ENSEMBLE_GAUSSIAN_MLP = 0, HIPETS_ENSEMBLE_BASIC = 1 };
 /* randomness source of a rollout */
-enum { HIPETS_MODE_EXACT = 0, /* reference semantics, injected perms / eps (parity mode)      */
-       HIPETS_MODE_FAST = 1   /* whole-horizon persistent kernel, in-kernel Philox (fast mode) */ };
+enum { HIPETS_MODE_EXACT = 0,  /* reference semantics, injected perms / eps (parity mode)                              */
+       HIPETS_MODE_FAST = 1,   /* whole-horizon kernel, block-balanced member schedule, in-kernel Philox             */
+       HIPETS_MODE_DEVICE = 2  /* reference semantics (ONE balanced permutation of all B rows per step,              */
+                               /* gaussian_mlp.py:203-205; iid eps per row and dim, model.py:471-473) with both      */
+                               /* drawn in-kernel from (seed, stream_id): a keyed bijection of [0, B) and Philox     */
+                               /* normals.  No input tensors; exportable through hipets_device_perms /              */
+                               /* hipets_fast_normals for replay through a reference implementation.                 */ };
 
 /*
  * Snapshot of what ModelEnv.evaluate_action_sequences reads from the live objects
@@ -102,7 +112,7 @@ typedef struct {
                              /*   gaussian_mlp.py:205); fixed_model [B] (:375); else NULL         */
     const float* eps;        /* DEVICE [H,B,out_dim] standard normals consumed by torch.normal    */
                              /*   (model.py:471-473); NULL => predictions are the mean            */
-    /* FAST mode: counter-based RNG                                                               */
+    /* FAST and DEVICE modes: counter-based RNG                                                   */
     uint64_t seed;
     uint64_t stream_id;      /* e.g. plan counter * iterations + iteration                        */
     const int32_t* member_schedule; /* DEVICE [H, n_workgroups] optional override (testing)       */
@@ -157,6 +167,13 @@ int hipets_fast_schedule(hipets_engine* e, int32_t horizon, int32_t n_workgroups
 int hipets_fast_normals(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id,
                         float* normals, void* stream);
 
+/* DEVICE-mode randomness, exported for replay: perms DEVICE int64 [H, B] (random_model; [1, B] for fixed_model) = the
+ * permutation a DEVICE rollout of `batch` = pop * particles rows with the same (seed, stream_id) uses at every step, in
+ * the reference's convention (slot j holds row perms[t][j]; slot j runs on active member j / (B / M)); the eps of that
+ * rollout are hipets_fast_normals(seed, stream_id).                                                              */
+int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id, int64_t* perms,
+                        void* stream);
+
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {
     int32_t population_size;
@@ -210,10 +227,33 @@ int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t horizon, int32_t act
 int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t horizon, int32_t act_dim, const float* kept, const float* mu,
                       const float* var, const float* end_noise, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 
+/* ---- fused plans: a whole optimizer.optimize() with the engine's rollout as objective -------- */
+/* Randomness mode of the rollouts inside the hipets_plan_* calls: HIPETS_MODE_FAST (default) or HIPETS_MODE_DEVICE
+ * (reference propagation semantics).  Iteration i of plan `plan_id` uses stream_id = plan_id * num_iterations + i for
+ * both its population noise and its rollout (iCEM: 4 * that, + 0..3 for noise / shifted tail / kept-elite draw / rollout). */
+int hipets_set_plan_mode(hipets_engine* e, int32_t mode);
+
+/* Optional per-iteration record of the following fused plans (single-environment plans; NULL pointers are skipped, a NULL
+ * trace switches recording off).  All DEVICE, written asynchronously on the plan's stream:
+ *   populations [iters, max_rows, H, A]  the candidates iteration i evaluated (rows beyond the iteration's size untouched)
+ *   values      [iters, max_rows]        their returns after the NaN filter
+ *   mus, dispersions [iters, H, A]       optimizer state after iteration i (MPPI: mus = the refined mean)
+ *   elite_idx   [iters, elite_num]       int32, best first (CEM / iCEM)
+ * This is what lets a test replay a fused plan through a reference implementation draw by draw.                      */
+typedef struct {
+    float* populations;
+    float* values;
+    float* mus;
+    float* dispersions;
+    int32_t* elite_idx;
+    int32_t max_rows;
+} hipets_plan_trace;
+int hipets_set_plan_trace(hipets_engine* e, const hipets_plan_trace* trace);
+
 /* Whole CEMOptimizer.optimize with the engine's rollout as objective, no host round trip
  * (replaces trajectory_opt.py:142-188 + the closure at :743-748).  x0/lower/upper DEVICE [H,A];
- * out DEVICE [H,A] = mu if return_mean_elites else best.  FAST mode rollouts; workspace is
- * engine-owned.                                                                               */
+ * out DEVICE [H,A] = mu if return_mean_elites else best.  Rollouts in the engine's plan mode;
+ * workspace is engine-owned.                                                                  */
 int hipets_plan_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower,
                     const float* upper, const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
                     float* out, void* stream);

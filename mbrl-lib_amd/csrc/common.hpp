@@ -60,4 +60,60 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Counter-based random permutation of [0, n): the device-side stand-in for the reference's per-step
+// torch.randperm(B) (mbrl/models/gaussian_mlp.py:203-205).  A mixed-radix alternating Feistel network on
+// [0, a) x [0, b) (a * b >= n, a ~ b ~ sqrt(n)) with cycle walking: every round adds a keyed hash of one half
+// to the other half modulo its radix, which is invertible whatever the hash, so x -> perm(x) is a bijection
+// of [0, a*b); re-applying it until the image falls below n restricts it to a bijection of [0, n).  O(1) per
+// element, no sort, no memory: every workgroup computes the rows it owns.  Balance (each member gets exactly
+// n / M rows) is exact by construction; uniformity is checked statistically (tests/test_perm_feistel.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPermRounds = 6;
+
+__host__ __device__ inline void perm_radices(uint32_t n, uint32_t* a, uint32_t* b) {
+    uint32_t r = 1;
+    while ((uint64_t)r * r < n) ++r;  // ceil(sqrt(n)); n < 2^31 so r < 46342
+    *a = r;
+    *b = (n + r - 1) / r;
+    if (*b < 1) *b = 1;
+}
+
+__host__ __device__ inline uint32_t perm_hash(uint32_t v, uint32_t k) {  // murmur3 finaliser of a keyed multiply
+    uint32_t h = v * 0x9E3779B1u + k;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// 64-bit mix (splitmix64 finaliser), host + device
+__host__ __device__ inline uint64_t perm_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// key of the permutation of (seed, stream, step); step = 0xFFFFFFFF for the one permutation of a TS-infinity rollout
+__host__ __device__ inline uint64_t perm_key(uint64_t seed, uint64_t stream, uint32_t step) {
+    return perm_mix64(seed ^ perm_mix64(stream * 0x9E3779B97F4A7C15ull + 0x5045524Dull /* "PERM" */) ^ ((uint64_t)step << 32));
+}
+
+__host__ __device__ inline uint32_t perm_apply(uint32_t x, uint32_t n, uint32_t a, uint32_t b, uint64_t key) {
+    uint32_t k[kPermRounds];
+#pragma unroll
+    for (int r = 0; r < kPermRounds; ++r) k[r] = (uint32_t)(perm_mix64(key + (uint64_t)r) >> 16);
+    do {
+        uint32_t L = x / b, R = x % b;  // x = L * b + R, L in [0, a), R in [0, b)
+#pragma unroll
+        for (int r = 0; r < kPermRounds; ++r) {
+            if (r & 1) { R += perm_hash(L, k[r]) % b; if (R >= b) R -= b; }  // R, hash % b < b < 2^16: no overflow
+            else { L += perm_hash(R, k[r]) % a; if (L >= a) L -= a; }
+        }
+        x = L * b + R;
+    } while (x >= n);
+    return x;
+}
+
 }  // namespace hipets

@@ -14,9 +14,9 @@
 
 #include "../../include/hipets.h"
 #include "cem.hpp"
+#include "launch.hpp"
 #include "optim.hpp"
-#include "planet.hpp"
-#include "rollout.hpp"
+#include "rollout_helpers.hpp"
 
 using namespace hipets;
 
@@ -86,23 +86,19 @@ struct hipets_engine {
     bool has_planet = false;
     PlanetDev pd{};
     DevBuf planet_w, planet_b, planet_member, planet_ops;
-    bool planet_lds_attr_set = false;
+    // fused plans: randomness mode of their rollouts, optional per-iteration trace
+    int plan_mode = HIPETS_MODE_FAST;
+    bool has_trace = false;
+    hipets_plan_trace trace{};
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
-    bool lds_attr_set[kMaxR + 1] = {false, false, false, false, false};
 };
 
 namespace {
 
-template <int R>
-int launch_rollout_r(hipets_engine* e, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
-    if (!e->lds_attr_set[R]) {
-        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<R>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_max));
-        e->lds_attr_set[R] = true;
-    }
+int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
     hipEvent_t a = nullptr, b = nullptr;
     if (e->timing) {
         if (!e->event_pool.empty()) {
@@ -113,26 +109,18 @@ int launch_rollout_r(hipets_engine* e, int grid, size_t lds, const RolloutArgs& 
             HCHECK(hipEventCreate(&a));
             HCHECK(hipEventCreate(&b));
         }
-        // the events ride on the dispatch packet itself (start / end timestamps of THIS kernel): no extra barrier
-        // packets around the launch, so timing does not perturb the plan it measures
-        hipExtLaunchKernelGGL(rollout_kernel<R>, dim3(grid), dim3(kThreads), (std::uint32_t)lds, st, a, b, 0u, e->md, ra);
-        HCHECK(hipGetLastError());
-        e->events.emplace_back(a, b);
-        return 0;
     }
-    hipLaunchKernelGGL(rollout_kernel<R>, dim3(grid), dim3(kThreads), lds, st, e->md, ra);
-    HCHECK(hipGetLastError());
-    return 0;
-}
-
-int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
+    hipError_t err;
     switch (R) {
-        case 1: return launch_rollout_r<1>(e, grid, lds, ra, st);
-        case 2: return launch_rollout_r<2>(e, grid, lds, ra, st);
-        case 3: return launch_rollout_r<3>(e, grid, lds, ra, st);
-        case 4: return launch_rollout_r<4>(e, grid, lds, ra, st);
+        case 1: err = launch_rollout_r1(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
+        case 2: err = launch_rollout_r2(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
+        case 3: err = launch_rollout_r3(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
+        case 4: err = launch_rollout_r4(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
         default: return fail("unsupported rows_per_group %d (1..%d)", R, kMaxR);
     }
+    if (e->timing) e->events.emplace_back(a, b);  // recorded (or leaked to the pool) either way
+    if (err != hipSuccess) return fail("rollout kernel launch failed: %s", hipGetErrorString(err));
+    return 0;
 }
 
 size_t lds_for(const hipets_engine* e, int R, int horizon) {
@@ -181,7 +169,7 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
     *sched = nullptr;
     *sched_stride = 0;
-    if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1) return 0;
+    if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
     const long long tiles = (pop + kTile - 1) / kTile;
     const int R = choose_R(e, tiles, P, 0, H);
     const int nwg = (int)((tiles + R - 1) / R) * P;
@@ -247,6 +235,21 @@ __global__ void unpad_shards_kernel(const float* gathered, float* values, int po
     const int r = i < split ? i / (base + 1) : extra + (i - split) / base;
     const int lo = r * base + min(r, extra);
     values[i] = gathered[(size_t)r * width + (i - lo)];
+}
+
+// hipets_set_plan_trace: record iteration i of a fused plan (population as evaluated, values after the NaN filter, refitted
+// mean / dispersion) into the caller's buffers.  A no-op unless a trace is set.
+int trace_iter(hipets_engine* e, int i, int rows, size_t nd, const float* population, const float* values, const float* mu,
+               const float* disp, hipStream_t st) {
+    if (!e->has_trace) return 0;
+    const hipets_plan_trace& t = e->trace;
+    if (rows > t.max_rows) return fail("plan trace: iteration %d evaluates %d candidates, trace buffers hold %d", i, rows, t.max_rows);
+    if (t.populations && population)
+        HCHECK(hipMemcpyAsync(t.populations + (size_t)i * t.max_rows * nd, population, (size_t)rows * nd * 4, hipMemcpyDeviceToDevice, st));
+    if (t.values && values) HCHECK(hipMemcpyAsync(t.values + (size_t)i * t.max_rows, values, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+    if (t.mus && mu) HCHECK(hipMemcpyAsync(t.mus + (size_t)i * nd, mu, nd * 4, hipMemcpyDeviceToDevice, st));
+    if (t.dispersions && disp) HCHECK(hipMemcpyAsync(t.dispersions + (size_t)i * nd, disp, nd * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
 }
 
 CemDev make_cem(const hipets_cem_params* p, int n_env = 1) {
@@ -504,14 +507,20 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     ra.phase_cycles = reinterpret_cast<long long*>(o->phase_cycles);
     ra.pop_env = n_env > 1 ? pop / n_env : 0;
 
-    if (o->mode == HIPETS_MODE_EXACT) {
+    if (o->mode == HIPETS_MODE_EXACT || o->mode == HIPETS_MODE_DEVICE) {
+        // Reference propagation semantics: per step ONE balanced permutation of all B rows, slot j -> member j / (B / M)
+        // (gaussian_mlp.py:164-166, 203-205).  EXACT takes the permutations and eps from the caller (the reference's own
+        // draws); DEVICE evaluates a keyed bijection and Philox normals in-kernel (no input tensors, no host work).
+        const bool device = o->mode == HIPETS_MODE_DEVICE;
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
         if (!md.iid_members && B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
             return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
                         "Current batch size is %lld for %d models.", B, md.M);
         if (!expectation) {
-            if (!o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
+            if (device && md.iid_members)
+                return fail("DEVICE mode has no BasicEnsemble (iid member map) variant: use FAST, or EXACT with injected maps");
+            if (!device && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
             if (md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
                 return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
         }
@@ -530,13 +539,33 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         ra.rows_per_domain = rpd;
         ra.state = e->state.as<float>();
         ra.term = e->term.as<unsigned char>();
-        ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
-        ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? (long long)domains * rpd : 0;
-        ra.eps = o->eps;
-        ra.use_philox = 0;
-        for (int t = 0; t < H; ++t) {
-            ra.t_begin = t;
-            ra.t_end = t + 1;
+        if (device) {
+            ra.perm = nullptr;
+            ra.eps = nullptr;
+            ra.use_philox = o->no_sample ? 0 : 1;
+            if (!expectation) {
+                ra.perm_n = (unsigned)B;
+                perm_radices((uint32_t)B, &ra.perm_a, &ra.perm_b);
+                ra.perm_fixed = md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0;
+            }
+        } else {
+            ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
+            ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? (long long)domains * rpd : 0;
+            ra.eps = o->eps;
+            ra.use_philox = 0;
+        }
+        // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
+        // (state through HBM); TS-infinity / expectation rollouts of DEVICE mode keep their rows and run as ONE launch
+        const bool per_step = !device || md.propagation == HIPETS_PROP_RANDOM_MODEL;
+        if (per_step) {
+            for (int t = 0; t < H; ++t) {
+                ra.t_begin = t;
+                ra.t_end = t + 1;
+                if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
+            }
+        } else {
+            ra.t_begin = 0;
+            ra.t_end = H;
             if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
         }
     } else if (o->mode == HIPETS_MODE_FAST) {
@@ -610,10 +639,13 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     ra.phase_cycles = nullptr;
     ra.t_begin = 0;
     ra.t_end = 1;
-    if (o->mode == HIPETS_MODE_EXACT) {
+    if (o->mode == HIPETS_MODE_EXACT || o->mode == HIPETS_MODE_DEVICE) {
+        const bool device = o->mode == HIPETS_MODE_DEVICE;
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
-        if (!expectation && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
+        if (!expectation && device && md.iid_members)
+            return fail("DEVICE mode has no BasicEnsemble (iid member map) variant: use FAST, or EXACT with injected maps");
+        if (!expectation && !device && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
         if (!expectation && md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
             return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
         const int rpd = expectation ? B : (md.iid_members ? o->rows_per_member : B / domains);
@@ -623,10 +655,19 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         ra.groups = (int)((tiles + R - 1) / R);
         ra.rows_per_domain = rpd;
-        ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
-        ra.perm_step = 0;
-        ra.eps = o->eps;
-        ra.use_philox = 0;
+        if (device) {  // a ModelEnv.step of a TS-infinity rollout keeps its member map: the caller keeps (seed, stream_id) fixed
+            ra.use_philox = o->no_sample ? 0 : 1;
+            if (!expectation) {
+                ra.perm_n = (unsigned)B;
+                perm_radices((uint32_t)B, &ra.perm_a, &ra.perm_b);
+                ra.perm_fixed = md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0;
+            }
+        } else {
+            ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
+            ra.perm_step = 0;
+            ra.eps = o->eps;
+            ra.use_philox = 0;
+        }
         if (launch_rollout(e, R, domains * ra.groups, lds, ra, st)) return 1;
     } else if (o->mode == HIPETS_MODE_FAST) {
         const long long tiles = (B + kTile - 1) / kTile;
@@ -679,6 +720,36 @@ int hipets_fast_normals(hipets_engine* e, int32_t H, int32_t B, uint64_t seed, u
     hipLaunchKernelGGL(export_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        normals, H, B, e->md.out_dim, (unsigned long long)seed, (unsigned long long)stream_id);
     HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_device_perms(hipets_engine* e, int32_t H, int32_t B, uint64_t seed, uint64_t stream_id, int64_t* perms, void* stream) {
+    if (!e || !e->has_model) return fail("engine has no model");
+    if (!perms || H < 1 || B < 1) return fail("bad argument");
+    HCHECK(hipSetDevice(e->device));
+    uint32_t a, b;
+    perm_radices((uint32_t)B, &a, &b);
+    const int fixed = e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0;
+    const int rows = fixed ? 1 : H;
+    const long long n = (long long)rows * B;
+    hipLaunchKernelGGL(export_perms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<long long*>(perms), rows, (unsigned)B, a, b, fixed, (unsigned long long)seed,
+                       (unsigned long long)stream_id);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_set_plan_mode(hipets_engine* e, int32_t mode) {
+    if (!e) return fail("null engine");
+    if (mode != HIPETS_MODE_FAST && mode != HIPETS_MODE_DEVICE) return fail("plan mode must be HIPETS_MODE_FAST or HIPETS_MODE_DEVICE");
+    e->plan_mode = mode;
+    return 0;
+}
+
+int hipets_set_plan_trace(hipets_engine* e, const hipets_plan_trace* t) {
+    if (!e) return fail("null engine");
+    e->has_trace = t != nullptr;
+    if (t) e->trace = *t;
     return 0;
 }
 
@@ -788,6 +859,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
+    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     const CemDev c = make_cem(p, n_env);
@@ -800,7 +872,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     HCHECK(hipGetLastError());
     HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
     hipets_rollout_opts ro{};
-    ro.mode = HIPETS_MODE_FAST;
+    ro.mode = e->plan_mode;
     ro.seed = seed;
     ro.n_env = n_env;
     int n2 = 1;
@@ -821,10 +893,13 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
         if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream,
                          sched ? sched + (size_t)i * sched_stride : nullptr))
             return 1;
+        int* eidx = (e->has_trace && n_env == 1 && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
         hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
-                           e->best_solution.as<float>(), (int*)nullptr);
+                           e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
+        if (n_env == 1 && trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st))
+            return 1;
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
@@ -849,7 +924,7 @@ int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_
                        e->past_action.as<float>());
     HCHECK(hipGetLastError());
     hipets_rollout_opts ro{};
-    ro.mode = HIPETS_MODE_FAST;
+    ro.mode = e->plan_mode;
     ro.seed = seed;
     const int* sched = nullptr;
     size_t sched_stride = 0;
@@ -864,6 +939,7 @@ int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_
                          sched ? sched + (size_t)k * sched_stride : nullptr))
             return 1;
         if (hipets_mppi_update(e, pop, H, A, gamma, e->values.as<float>(), e->population.as<float>(), mean, stream)) return 1;
+        if (trace_iter(e, k, pop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st)) return 1;
     }
     return 0;
 }
@@ -912,8 +988,10 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
     HCHECK(hipGetLastError());
     HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
     hipets_rollout_opts ro{};
-    ro.mode = HIPETS_MODE_FAST;
+    ro.mode = e->plan_mode;
     ro.seed = seed;
+    if (e->s0.ensure((size_t)e->md.obs_dim * 4)) return 1;  // the observation is the same for every iteration: stage it once
+    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)e->md.obs_dim * 4, hipMemcpyHostToDevice, st));
     float* popbuf = e->population.as<float>();
     for (int i = 0; i < iters; ++i) {
         const int n = sizes[i];
@@ -946,7 +1024,7 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         }
         const int rows = n + extra;
         ro.stream_id = sid + 3;
-        if (hipets_rollout(e, popbuf, s0, rows, H, P, &ro, e->values.as<float>(), stream)) return 1;
+        if (rollout_impl(e, popbuf, nullptr, rows, H, P, &ro, e->values.as<float>(), stream, nullptr)) return 1;  // s0 staged above
         cp.population_size = rows;
         if (check_cem(&cp)) return 1;
         int n2 = 1;
@@ -957,6 +1035,9 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         HCHECK(hipGetLastError());
         if (hipets_gather_rows(e, K, (int32_t)nd, popbuf, e->elite_idx.as<int32_t>(), elite, stream)) return 1;  // :476
         has_elite = 1;
+        if (trace_iter(e, i, rows, nd, popbuf, e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st)) return 1;
+        if (e->has_trace && e->trace.elite_idx)
+            HCHECK(hipMemcpyAsync(e->trace.elite_idx + (size_t)i * K, e->elite_idx.p, (size_t)K * 4, hipMemcpyDeviceToDevice, st));
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
@@ -1064,14 +1145,8 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     ra.trace_belief = o->trace_belief;
     ra.trace_rewards = o->trace_rewards;
     const size_t lds = planet_smem_bytes(e->pd.ld);
-    if (!e->planet_lds_attr_set) {
-        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(planet_rollout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)e->lds_max));
-        e->planet_lds_attr_set = true;
-    }
     const int nwg = (int)((B + kTile - 1) / kTile);
-    hipLaunchKernelGGL(planet_rollout_kernel, dim3(nwg), dim3(kThreads), lds, st, e->pd, ra);
-    HCHECK(hipGetLastError());
+    HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st));
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
     return 0;
@@ -1139,7 +1214,7 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
     HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
     hipets_rollout_opts ro{};
-    ro.mode = HIPETS_MODE_FAST;
+    ro.mode = e->plan_mode;
     ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_cem)
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;

@@ -73,6 +73,8 @@ struct RolloutArgs {
     unsigned char* term;   // EXACT: [B] in/out
     const long long* perm; // EXACT: [H,B] / [B] / null
     long long perm_step;   // stride between steps (0 for fixed_model)
+    unsigned perm_n, perm_a, perm_b;  // DEVICE mode: row of slot j = perm_apply(j) over [0, perm_n), radices a x b (perm_n = 0: none)
+    int perm_fixed;        // DEVICE mode: one permutation for the whole horizon (fixed_model) instead of one per step
     const float* eps;      // [H,B,out] or null
     int use_philox;        // FAST without eps override
     unsigned long long seed, stream_id;
@@ -130,7 +132,8 @@ struct GemmFrags {
     f32x4 ax[EX > 0 ? EX : 1];
 };
 
-template <int R, int CT, int EX>
+// ACT >= 0: the activation is a compile-time fact (one epilogue in the code); ACT < 0: `act` selects it at run time.
+template <int R, int CT, int EX, int ACT>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC,
                                           const int tail_steps, const int c_first, const Extras ex,
@@ -301,7 +304,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     if (!apply_act) {
         store([](const f32x4 a) { return a; });
     } else {
-        switch (act) {
+        switch (ACT >= 0 ? ACT : act) {
             case HIPETS_ACT_SILU:  // x * rcp(1 + exp2(-x log2 e)): the two multiplies and the add as packed 2 x f32 ops
                 store([](const f32x4 a) {
                     using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -326,24 +329,24 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     prof.mark(13);
 }
 
-template <int R, int CT>
+template <int R, int CT, int ACT>
 __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* out, int ld, const float* W,
                                              const float* bias, int KC, int tail_steps, int c_first, const Extras ex,
                                              bool apply_act, int act, float slope, int lane, Prof& prof) {
     switch (nex) {
         case 0:
-            if constexpr (CT > 0) wave_gemm<R, CT, 0>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
+            if constexpr (CT > 0) wave_gemm<R, CT, 0, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
             break;
-        case 1: wave_gemm<R, CT, 1>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        case 2: wave_gemm<R, CT, 2>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        case 3: wave_gemm<R, CT, 3>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        default: wave_gemm<R, CT, 4>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 1: wave_gemm<R, CT, 1, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 2: wave_gemm<R, CT, 2, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 3: wave_gemm<R, CT, 3, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        default: wave_gemm<R, CT, 4, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
     }
 }
 
 // One linear op (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS), both with row stride ld.
 // W / bias point at the packed fragments / padded biases of this op (pack_weights_kernel / pack_bias_kernel).
-template <int R>
+template <int R, int ACT = -1>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
                                           const int lane, Prof& prof) {
@@ -363,29 +366,29 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
     constexpr int kMaxCT = kWaves >= 8 ? 2 : 3;
     int done = 0;
     while (full - done > kMaxCT) {
-        wave_gemm<R, kMaxCT, 0>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
+        wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
         done += kMaxCT;
     }
     const int c_first = wave + kWaves * done;
     switch (full - done) {
-        case 0: wave_gemm_ex<R, 0>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-        case 1: wave_gemm_ex<R, 1>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-        case 2: wave_gemm_ex<R, 2>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+        case 0: wave_gemm_ex<R, 0, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+        case 1: wave_gemm_ex<R, 1, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+        case 2: wave_gemm_ex<R, 2, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
         default:
             if constexpr (kMaxCT >= 3)
-                wave_gemm_ex<R, 3>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+                wave_gemm_ex<R, 3, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
             break;
     }
 }
 
 // Layer l of the ensemble MLP with member `member`'s weights.
-template <int R>
+template <int R, int ACT>
 __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
                                           const float* in, float* out, const int wave, const int lane, Prof& prof) {
     const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
     const float* W = md.w + (size_t)member * md.wmember + lm.woff;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
-    linear_op<R>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
+    linear_op<R, ACT>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
 }
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
@@ -522,8 +525,19 @@ __device__ __forceinline__ float softplus_fast(float x) {
     return x > 20.0f ? x : y;
 }
 
-template <int R>
-__global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
+// Minimum waves per SIMD the register allocation must leave room for (= workgroups of 4 waves per CU).  R <= 2 keeps two
+// workgroups per CU resident (their barrier / latency phases overlap); R = 3, 4 need the registers.
+#ifndef HIPETS_MINWAVES_R1
+#define HIPETS_MINWAVES_R1 2
+#endif
+#ifndef HIPETS_MINWAVES_R2
+#define HIPETS_MINWAVES_R2 2
+#endif
+template <int R> struct MinWaves { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
+
+// ACT = HIPETS_ACT_* : kernel specialised for that activation; ACT = -1: md.activation is read at run time.
+template <int R, int ACT>
+__global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RolloutSmem sm;
@@ -569,12 +583,14 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
         const long long* perm = ra.perm ? ra.perm + (long long)ra.t_begin * ra.perm_step : nullptr;
         // unbalanced member maps (BasicEnsemble) pad every member's slots with -1 at the tail: nothing to do here
         if (perm && perm[(long long)domain * ra.rows_per_domain + j0] < 0) return;
+        // DEVICE mode: the step's permutation is a keyed bijection evaluated on the fly (common.hpp perm_apply)
+        const unsigned long long pkey = ra.perm_n ? perm_key(ra.seed, ra.stream_id, ra.perm_fixed ? 0xFFFFFFFFu : (unsigned)ra.t_begin) : 0ull;
         for (int s = tid; s < ROWS; s += kThreads) {
             const int j = j0 + s;
             int rid = -1;
             if (j < ra.rows_per_domain) {
                 const int jj = domain * ra.rows_per_domain + j;
-                rid = perm ? (int)perm[jj] : jj;
+                rid = perm ? (int)perm[jj] : (ra.perm_n ? (int)perm_apply((unsigned)jj, ra.perm_n, ra.perm_a, ra.perm_b, pkey) : jj);
             }
             sm.rowid[s] = rid;
         }
@@ -734,7 +750,7 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             float* nxt = sm.buf1;
             for (int l = 0; l < md.n_layers; ++l) {
                 prof.mark(12);
-                mlp_layer<R>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                mlp_layer<R, ACT>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
@@ -870,108 +886,6 @@ __global__ __launch_bounds__(kThreads) void rollout_kernel(const ModelDev md, co
             if (rid >= 0) ra.state[(size_t)rid * md.obs_dim + d] = sm.state[i];
         }
     }
-}
-
-// ---- small helper kernels ---------------------------------------------------------------------------
-
-// model_env.py:170-176: tile s0, zero the accumulators (EXACT mode state lives in HBM between steps)
-__global__ void init_state_kernel(float* state, float* totals, unsigned char* term, const float* s0, int B, int obs_dim) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B * obs_dim) state[i] = s0[i % obs_dim];
-    if (i < B) { totals[i] = 0.f; term[i] = 0; }
-}
-
-// model_env.py:190-191: total_rewards.reshape(-1, P).mean(dim=1)
-__global__ void particle_mean_kernel(const float* totals, float* returns, int pop, int P) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= pop) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += totals[(size_t)c * P + p];
-    returns[c] = s / (float)P;
-}
-
-// FAST-mode member schedule: per step a balanced random assignment of workgroups to member slots
-// (every slot gets floor/ceil(nWG/M) workgroups -- the reference's "each model gets exactly the same
-// number of samples", gaussian_mlp.py:267-275, at 16*R-row granularity).  fixed_model: one draw
-// for all steps (TS-infinity).  One block per step.
-// BasicEnsemble (iid != 0): every workgroup draws its slot independently and uniformly (randint,
-// basic_ensemble.py:122-129), no balancing.
-__global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, int iid, unsigned long long seed,
-                                       unsigned long long stream_id) {
-    extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
-    const int t = blockIdx.x;
-    // blockIdx.y: consecutive rollouts of one plan (stream ids stream_id, stream_id + 1, ...), schedules back to back
-    stream_id += blockIdx.y;
-    sched += (size_t)blockIdx.y * gridDim.x * nwg;
-    const unsigned long long tk = fixed ? 0xFFFFFFFFull : (unsigned long long)t;
-    const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
-    for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
-    __syncthreads();
-    if (iid) {
-        for (int me = threadIdx.x; me < nwg; me += blockDim.x)
-            sched[(size_t)t * nwg + me] = (int)(((keys[me] >> 32) * (unsigned long long)M) >> 32);
-        return;
-    }
-    for (int me = threadIdx.x; me < nwg; me += blockDim.x) {
-        const unsigned long long kme = keys[me];
-        int rank = 0;
-        for (int i = 0; i < nwg; ++i) {
-            const unsigned long long ki = keys[i];
-            rank += (ki < kme) || (ki == kme && i < me);
-        }
-        sched[(size_t)t * nwg + me] = (int)(((long long)rank * M) / nwg);
-    }
-}
-
-// export of the FAST-mode normals (hipets_fast_normals): out[t][rid][d]
-__global__ void export_normals_kernel(float* out, int H, int B, int out_dim, unsigned long long seed,
-                                      unsigned long long stream_id) {
-    const int nblk = (out_dim + 3) / 4;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)H * B * nblk) return;
-    const int blk = (int)(i % nblk);
-    const int rid = (int)((i / nblk) % B);
-    const int t = (int)(i / ((long long)nblk * B));
-    float nrm[4];
-    rollout_normals4(rid, t, blk, seed, stream_id, nrm);
-    for (int q = 0; q < 4; ++q) {
-        const int d = blk * 4 + q;
-        if (d < out_dim) out[((size_t)t * B + rid) * out_dim + d] = nrm[q];
-    }
-}
-
-// Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
-//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
-// so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
-// src_nk != 0: the source is [E, N, K] row-major (nn.Linear's [out, in]) instead of [E, K, N] (EnsembleLinearLayer).
-__global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
-                                    int Np, long long member_stride, long long layer_off, int permute_cols, int src_nk) {
-    const long long per_member = (long long)Kp * Np;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_member * M) return;
-    const int m = (int)(i / per_member);
-    long long r = i % per_member;
-    const int s = (int)(r & 3); r >>= 2;
-    const int lane = (int)(r & 63); r >>= 6;
-    const int KC = Kp / 16;
-    const int kk = (int)(r % KC);
-    const int c = (int)(r / KC);
-    const int k = 16 * kk + 4 * s + (lane >> 4);  // MFMA k-step s of a chunk covers k = 16 kk + 4 s + {0,1,2,3}
-    // fragment row (lane & 15) = index m of the transposed product D^T[m][batch row]; hidden layers map it to the
-    // real column lds_col(m) so that accumulator register i of lane group g lands on LDS position 4g + i
-    const int n = 16 * c + (permute_cols ? lds_col(lane & 15) : (lane & 15));
-    float v = 0.f;
-    if (k < K && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
-    dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
-}
-
-__global__ void pack_bias_kernel(float* dst, const float* src, const int* members, int M, int N, int Np, int member_stride,
-                                 int layer_off, int permute_cols) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * Np) return;
-    const int m = i / Np, np_ = i % Np;
-    const int n = permute_cols ? lds_col(np_) : np_;  // same permutation as the weight columns
-    dst[(size_t)m * member_stride + layer_off + np_] = n < N ? src[(size_t)members[m] * N + n] : 0.f;
 }
 
 }  // namespace hipets

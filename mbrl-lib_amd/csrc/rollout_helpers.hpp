@@ -1,0 +1,121 @@
+// rollout_helpers.hpp -- the small kernels around the rollout kernel (state init, particle mean, member schedules, exports of
+// the device-side randomness, weight / bias packing).  Included by hipets.hip only (non-template kernels: one definition).
+#pragma once
+#include "rollout.hpp"
+
+namespace hipets {
+
+// ---- small helper kernels ---------------------------------------------------------------------------
+
+// model_env.py:170-176: tile s0, zero the accumulators (EXACT mode state lives in HBM between steps)
+__global__ void init_state_kernel(float* state, float* totals, unsigned char* term, const float* s0, int B, int obs_dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * obs_dim) state[i] = s0[i % obs_dim];
+    if (i < B) { totals[i] = 0.f; term[i] = 0; }
+}
+
+// model_env.py:190-191: total_rewards.reshape(-1, P).mean(dim=1)
+__global__ void particle_mean_kernel(const float* totals, float* returns, int pop, int P) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= pop) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += totals[(size_t)c * P + p];
+    returns[c] = s / (float)P;
+}
+
+// FAST-mode member schedule: per step a balanced random assignment of workgroups to member slots
+// (every slot gets floor/ceil(nWG/M) workgroups -- the reference's "each model gets exactly the same
+// number of samples", gaussian_mlp.py:267-275, at 16*R-row granularity).  fixed_model: one draw
+// for all steps (TS-infinity).  One block per step.
+// BasicEnsemble (iid != 0): every workgroup draws its slot independently and uniformly (randint,
+// basic_ensemble.py:122-129), no balancing.
+__global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, int iid, unsigned long long seed,
+                                       unsigned long long stream_id) {
+    extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
+    const int t = blockIdx.x;
+    // blockIdx.y: consecutive rollouts of one plan (stream ids stream_id, stream_id + 1, ...), schedules back to back
+    stream_id += blockIdx.y;
+    sched += (size_t)blockIdx.y * gridDim.x * nwg;
+    const unsigned long long tk = fixed ? 0xFFFFFFFFull : (unsigned long long)t;
+    const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
+    for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
+    __syncthreads();
+    if (iid) {
+        for (int me = threadIdx.x; me < nwg; me += blockDim.x)
+            sched[(size_t)t * nwg + me] = (int)(((keys[me] >> 32) * (unsigned long long)M) >> 32);
+        return;
+    }
+    for (int me = threadIdx.x; me < nwg; me += blockDim.x) {
+        const unsigned long long kme = keys[me];
+        int rank = 0;
+        for (int i = 0; i < nwg; ++i) {
+            const unsigned long long ki = keys[i];
+            rank += (ki < kme) || (ki == kme && i < me);
+        }
+        sched[(size_t)t * nwg + me] = (int)(((long long)rank * M) / nwg);
+    }
+}
+
+// export of the FAST-mode normals (hipets_fast_normals): out[t][rid][d]
+__global__ void export_normals_kernel(float* out, int H, int B, int out_dim, unsigned long long seed,
+                                      unsigned long long stream_id) {
+    const int nblk = (out_dim + 3) / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * B * nblk) return;
+    const int blk = (int)(i % nblk);
+    const int rid = (int)((i / nblk) % B);
+    const int t = (int)(i / ((long long)nblk * B));
+    float nrm[4];
+    rollout_normals4(rid, t, blk, seed, stream_id, nrm);
+    for (int q = 0; q < 4; ++q) {
+        const int d = blk * 4 + q;
+        if (d < out_dim) out[((size_t)t * B + rid) * out_dim + d] = nrm[q];
+    }
+}
+
+// export of the DEVICE-mode permutations (hipets_device_perms): out[t][j] = row that slot j holds at step t, i.e. the
+// tensor the reference would have drawn with torch.randperm(B) at that step (int64 like torch)
+__global__ void export_perms_kernel(long long* out, int H, unsigned n, unsigned a, unsigned b, int fixed, unsigned long long seed,
+                                    unsigned long long stream_id) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)H * n) return;
+    const int t = (int)(i / n);
+    const unsigned j = (unsigned)(i % n);
+    out[i] = (long long)perm_apply(j, n, a, b, perm_key(seed, stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t));
+}
+
+// Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
+//   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
+// so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
+// src_nk != 0: the source is [E, N, K] row-major (nn.Linear's [out, in]) instead of [E, K, N] (EnsembleLinearLayer).
+__global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
+                                    int Np, long long member_stride, long long layer_off, int permute_cols, int src_nk) {
+    const long long per_member = (long long)Kp * Np;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_member * M) return;
+    const int m = (int)(i / per_member);
+    long long r = i % per_member;
+    const int s = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int KC = Kp / 16;
+    const int kk = (int)(r % KC);
+    const int c = (int)(r / KC);
+    const int k = 16 * kk + 4 * s + (lane >> 4);  // MFMA k-step s of a chunk covers k = 16 kk + 4 s + {0,1,2,3}
+    // fragment row (lane & 15) = index m of the transposed product D^T[m][batch row]; hidden layers map it to the
+    // real column lds_col(m) so that accumulator register i of lane group g lands on LDS position 4g + i
+    const int n = 16 * c + (permute_cols ? lds_col(lane & 15) : (lane & 15));
+    float v = 0.f;
+    if (k < K && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
+    dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
+}
+
+__global__ void pack_bias_kernel(float* dst, const float* src, const int* members, int M, int N, int Np, int member_stride,
+                                 int layer_off, int permute_cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * Np) return;
+    const int m = i / Np, np_ = i % Np;
+    const int n = permute_cols ? lds_col(np_) : np_;  // same permutation as the weight columns
+    dst[(size_t)m * member_stride + layer_off + np_] = n < N ? src[(size_t)members[m] * N + n] : 0.f;
+}
+
+}  // namespace hipets

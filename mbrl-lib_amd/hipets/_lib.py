@@ -6,9 +6,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipets.so")
+# HIPETS_LIB selects another build of the SAME library (kernel-variant experiments under profiles/); there is no fallback
+LIB_PATH = os.environ.get("HIPETS_LIB") or os.path.join(_HERE, "libhipets.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LAYERS = 8
 
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -18,7 +19,8 @@ REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendu
 TERM = {"no_termination": 0, "cartpole": 1, "inverted_pendulum": 2, "hopper": 3, "walker2d": 4, "ant": 5, "humanoid": 6}
 NORM = {"none": 0, "f32": 1, "f64": 2}
 ENSEMBLE = {"gaussian_mlp": 0, "basic_ensemble": 1}
-MODE_EXACT, MODE_FAST = 0, 1
+MODE_EXACT, MODE_FAST, MODE_DEVICE = 0, 1, 2
+MODES = {"exact": MODE_EXACT, "fast": MODE_FAST, "device": MODE_DEVICE}
 
 
 class ModelDesc(C.Structure):
@@ -69,6 +71,11 @@ class IcemParams(C.Structure):
     ]
 
 
+class PlanTrace(C.Structure):
+    _fields_ = [("populations", C.c_void_p), ("values", C.c_void_p), ("mus", C.c_void_p), ("dispersions", C.c_void_p),
+                ("elite_idx", C.c_void_p), ("max_rows", C.c_int32)]
+
+
 _PLANET_TENSORS = ("w_embed", "b_embed", "w_ih", "b_ih", "w_hh", "b_hh", "w_prior1", "b_prior1", "w_prior2", "b_prior2",
                    "w_rew1", "b_rew1", "w_rew2", "b_rew2", "w_rew3", "b_rew3")
 
@@ -96,6 +103,9 @@ SYMBOLS = {
     "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_fast_schedule": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_device_perms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_set_plan_mode": (C.c_int, [_P, C.c_int32]),
+    "hipets_set_plan_trace": (C.c_int, [_P, C.POINTER(PlanTrace)]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
     "hipets_gather_rows": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),

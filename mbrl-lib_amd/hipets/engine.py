@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CemParams, HipetsError, ModelDesc, RolloutOpts
+from ._lib import CemParams, HipetsError, ModelDesc, PlanTrace, RolloutOpts
 from .model import ModelSpec
 
 
@@ -68,6 +68,8 @@ class Engine:
         self.spec: Optional[ModelSpec] = None
         self.planet_spec = None
         self.comm_world, self.comm_rank = 1, 0
+        self.plan_mode = "fast"
+        self._trace = None
         self._keep = []  # device tensors that must outlive async set_model work
 
     def close(self):
@@ -159,9 +161,11 @@ class Engine:
         B = pop * num_particles
         o = RolloutOpts()
         o.n_env = int(n_env)
-        o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
-        if mode not in ("exact", "fast"):
-            raise ValueError("mode must be 'exact' or 'fast'")
+        if mode not in _lib.MODES:
+            raise ValueError("mode must be 'exact', 'fast' or 'device'")
+        o.mode = _lib.MODES[mode]
+        if mode == "device" and (perms is not None or eps is not None or members is not None):
+            raise ValueError("mode='device' draws its permutations and eps in-kernel: perms / eps / members must be None")
         if members is not None:
             if self.spec.ensemble_kind != "basic_ensemble" or mode != "exact" or perms is not None:
                 raise ValueError("members= is the EXACT-mode input of BasicEnsemble models (GaussianMLP takes perms=)")
@@ -178,7 +182,7 @@ class Engine:
             _check_dev(eps, torch.float32, dev, "eps", (H, B, self.spec.out_dim))
         if mode == "exact":
             o.perms, o.eps = _ptr(perms), _ptr(eps)
-        else:
+        elif mode == "fast":
             o.fast_eps = _ptr(eps)
             if member_schedule is not None:
                 nwg, _ = self.fast_geometry(pop, num_particles, H, rows_per_group)
@@ -218,11 +222,16 @@ class Engine:
         _check_dev(obs, torch.float32, dev, "obs", (B, self.spec.obs_dim))
         _check_dev(actions, torch.float32, dev, "actions", (B, self.spec.act_dim))
         o = RolloutOpts()
-        o.mode = _lib.MODE_EXACT if mode == "exact" else _lib.MODE_FAST
+        if mode not in _lib.MODES:
+            raise ValueError("mode must be 'exact', 'fast' or 'device'")
+        o.mode = _lib.MODES[mode]
         o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
         o.rows_per_group = int(rows_per_group)
         o.no_sample = int(not sample)
-        if mode == "exact":
+        if mode == "device":
+            if perm is not None or eps is not None or members is not None:
+                raise ValueError("mode='device' draws its permutation and eps in-kernel")
+        elif mode == "exact":
             if members is not None:
                 if self.spec.ensemble_kind != "basic_ensemble" or perm is not None or tuple(members.shape) != (B,):
                     raise ValueError("members= must be int64 [B] and the model a BasicEnsemble (GaussianMLP takes perm=)")
@@ -272,6 +281,43 @@ class Engine:
             _lib.check(self._lib.hipets_fast_normals(self._h, horizon, batch, int(seed) & (2**64 - 1),
                                                      int(stream_id) & (2**64 - 1), _ptr(out), _stream(self.device)))
         return out
+
+    def device_perms(self, horizon: int, batch: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:
+        """The permutations a DEVICE-mode rollout with (seed, stream_id) uses, in the reference's convention
+        (``model_shuffle_indices``): int64 [H, B] for random_model, [B] for fixed_model."""
+        fixed = self.spec.propagation == "fixed_model"
+        out = torch.empty(1 if fixed else horizon, batch, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.hipets_device_perms(self._h, horizon, batch, int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1),
+                                                     _ptr(out), _stream(self.device)))
+        return out[0] if fixed else out
+
+    def set_plan_mode(self, mode: str):
+        """Randomness mode of the rollouts inside the fused plans: 'fast' or 'device'."""
+        if mode not in ("fast", "device"):
+            raise ValueError("plan mode must be 'fast' or 'device'")
+        _lib.check(self._lib.hipets_set_plan_mode(self._h, _lib.MODES[mode]))
+        self.plan_mode = mode
+
+    def set_plan_trace(self, iters: int = 0, max_rows: int = 0, horizon: int = 0, act_dim: int = 0, elite_num: int = 0):
+        """Record the following fused plans iteration by iteration (hipets_set_plan_trace); returns the dict of device
+        tensors the library writes into.  ``iters=0`` switches recording off."""
+        if iters <= 0:
+            _lib.check(self._lib.hipets_set_plan_trace(self._h, None))
+            self._trace = None
+            return None
+        dev = self.device
+        tr = {"populations": torch.zeros(iters, max_rows, horizon, act_dim, device=dev),
+              "values": torch.zeros(iters, max_rows, device=dev),
+              "mus": torch.zeros(iters, horizon, act_dim, device=dev),
+              "dispersions": torch.zeros(iters, horizon, act_dim, device=dev),
+              "elite_idx": torch.zeros(iters, max(1, elite_num), dtype=torch.int32, device=dev)}
+        t = PlanTrace()
+        t.populations, t.values, t.mus = tr["populations"].data_ptr(), tr["values"].data_ptr(), tr["mus"].data_ptr()
+        t.dispersions, t.elite_idx, t.max_rows = tr["dispersions"].data_ptr(), tr["elite_idx"].data_ptr(), int(max_rows)
+        _lib.check(self._lib.hipets_set_plan_trace(self._h, C.byref(t)))
+        self._trace = tr  # keeps the buffers alive while the library holds their addresses
+        return tr
 
     # ---- optimizer pieces ---------------------------------------------------------------------------
     @staticmethod

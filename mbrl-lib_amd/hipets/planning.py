@@ -47,16 +47,24 @@ class HipTrajectoryEvalFn:
     """``trajectory_eval_fn(initial_state, action_sequences) -> Tensor[B]`` (mbrl/types.py:15).
 
     Built from a live ``mbrl.models.ModelEnv`` (weights are re-snapshotted whenever
-    ``ModelTrainer.train`` changed them) or from a ``ModelSpec``.  ``mode='fast'`` draws randomness
-    in-kernel (Philox keyed by ``seed`` and a per-call counter); ``mode='exact'`` reproduces the
-    reference's row->member maps from torch's RNGs, consumed in the reference's order
-    (one ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``);
-    ``mode='exact_device'`` keeps the reference's exact semantics (global balanced permutation per step) but draws
-    on the device, for users who want reference-identical propagation statistics at GPU speed.
+    ``ModelTrainer.train`` changed them) or from a ``ModelSpec``.  Randomness modes:
+
+    * ``'device'``: the reference's propagation semantics -- ONE balanced random permutation of all
+      ``pop * particles`` rows per step (gaussian_mlp.py:203-205), iid eps per row and dim -- with both drawn
+      in-kernel from ``(seed, call counter)`` (a keyed bijection + Philox).  One launch per step.
+    * ``'fast'``: one launch for the whole horizon; each workgroup (particle p of 16-48 consecutive candidates)
+      draws one member per step from a balanced schedule: same marginals, block-wise common random numbers.
+    * ``'exact'``: replays the reference's own draws from torch's RNGs in the reference's order (one
+      ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``): seed-identical
+      to ``ModelEnv.evaluate_action_sequences`` (a parity aid: it synchronises with the host).
+    * ``'exact_device'``: alias of ``'device'`` (kept for round-1 callers; BasicEnsemble models draw their iid
+      member maps with torch's device generator).
     """
 
     def __init__(self, model, num_particles: int, engine: Optional[Engine] = None, mode: str = "fast",
                  seed: int = 0, device=None, rng: Optional[torch.Generator] = None):
+        if mode not in ("fast", "device", "exact", "exact_device"):
+            raise ValueError("mode must be 'fast', 'device', 'exact' or 'exact_device'")
         self.num_particles = int(num_particles)
         self.mode = mode
         self.seed = int(seed)
@@ -90,43 +98,53 @@ class HipTrajectoryEvalFn:
             self.engine.set_model(self.spec)
             self._version = v
 
-    def __call__(self, initial_state: np.ndarray, action_sequences: torch.Tensor) -> torch.Tensor:
+    def _prep(self, action_sequences: torch.Tensor) -> torch.Tensor:
         self.refresh()
         if self.engine.spec is not self.spec:  # engine shared with another eval fn
             self.engine.set_model(self.spec)
         a = action_sequences
         if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
-        self.calls += 1
         self.check_batch(a.shape[0])
-        if self.mode == "exact_device":
-            # the reference's exact propagation semantics (one GLOBAL balanced random permutation of all rows per step,
-            # gaussian_mlp.py:203-205; i.i.d. eps per row and dim) with the draws made by torch's device generator:
-            # argsort of uniforms = a uniform random permutation.  Pure index / noise plumbing, no host round trip.
+        return a
+
+    @property
+    def kernel_mode(self) -> Optional[str]:
+        """'fast' / 'device' when the objective draws its randomness in-kernel from (seed, stream_id) -- the modes the
+        fused plans can run --, else None."""
+        if self.mode == "fast":
+            return "fast"
+        if self.mode in ("device", "exact_device") and (self.spec.ensemble_kind != "basic_ensemble" or self.spec.propagation == "expectation"):
+            return "device"
+        return None
+
+    def evaluate_seeded(self, initial_state: np.ndarray, action_sequences: torch.Tensor, seed: int, stream_id: int) -> torch.Tensor:
+        """One objective evaluation with explicit counter-based randomness: what iteration ``stream_id`` of a fused plan
+        runs, callable from the per-iteration optimizer paths so that both produce the same numbers bit for bit."""
+        a = self._prep(action_sequences)
+        return self.engine.rollout(a, initial_state, self.num_particles, mode=self.kernel_mode, seed=seed, stream_id=stream_id)
+
+    def __call__(self, initial_state: np.ndarray, action_sequences: torch.Tensor) -> torch.Tensor:
+        a = self._prep(action_sequences)
+        self.calls += 1
+        if self.kernel_mode is not None:
+            return self.engine.rollout(a, initial_state, self.num_particles, mode=self.kernel_mode, seed=self.seed, stream_id=self.calls)
+        if self.mode in ("device", "exact_device"):
+            # BasicEnsemble models only (GaussianMLP models take the in-kernel 'device' mode above): the reference's iid
+            # randint member maps (basic_ensemble.py:122-129, 255-260) and eps drawn by torch's device generator
             pop, H, _ = a.shape
             B = pop * self.num_particles
             g = self._device_rng()
-            perms = eps = None
-            if self.spec.ensemble_kind == "basic_ensemble":  # iid randint member maps (basic_ensemble.py:122-129, 255-260)
-                members = None
-                M = len(self.spec.members)
-                if self.spec.propagation == "random_model":
-                    members = torch.randint(M, (H, B), device=self.device, generator=g)
-                elif self.spec.propagation == "fixed_model":
-                    members = torch.randint(M, (B,), device=self.device, generator=g)
-                if not self.spec.deterministic:
-                    eps = torch.randn(H, B, self.spec.out_dim, device=self.device, generator=g)
-                return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", members=members, eps=eps)
+            eps = None
+            members = None
+            M = len(self.spec.members)
             if self.spec.propagation == "random_model":
-                perms = torch.rand(H, B, device=self.device, generator=g).argsort(dim=1)
+                members = torch.randint(M, (H, B), device=self.device, generator=g)
             elif self.spec.propagation == "fixed_model":
-                perms = torch.rand(B, device=self.device, generator=g).argsort()
+                members = torch.randint(M, (B,), device=self.device, generator=g)
             if not self.spec.deterministic:
                 eps = torch.randn(H, B, self.spec.out_dim, device=self.device, generator=g)
-            return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", perms=perms, eps=eps)
-        if self.mode == "fast":
-            return self.engine.rollout(a, initial_state, self.num_particles, mode="fast", seed=self.seed,
-                                       stream_id=self.calls)
+            return self.engine.rollout(a, initial_state, self.num_particles, mode="exact", members=members, eps=eps)
         pop, H, _ = a.shape
         B = pop * self.num_particles
         perms = eps = None
@@ -446,7 +464,7 @@ class _BoundObjective:
 
 def _fused_target(obj_fun) -> Optional[HipTrajectoryEvalFn]:
     if isinstance(obj_fun, _BoundObjective) and isinstance(obj_fun.eval_fn, HipTrajectoryEvalFn):
-        if obj_fun.eval_fn.mode == "fast":
+        if obj_fun.eval_fn.kernel_mode is not None:
             return obj_fun.eval_fn
     return None
 
@@ -459,6 +477,8 @@ def _prepare_fused(fused: HipTrajectoryEvalFn, population_sizes: Sequence[int]):
         fused.check_batch(int(n))
     if fused.engine.spec is not fused.spec:
         fused.engine.set_model(fused.spec)
+    if fused.engine.plan_mode != fused.kernel_mode:
+        fused.engine.set_plan_mode(fused.kernel_mode)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -470,6 +490,14 @@ class Optimizer:  # trajectory_opt.py:21-40
 
     def optimize(self, obj_fun, x0=None, callback=None, **kwargs) -> torch.Tensor:
         raise NotImplementedError
+
+
+def _default_seed(seed: Optional[int]) -> int:
+    """Seed of an optimizer's counter-based streams.  ``None`` draws one from torch's global generator (as the reference
+    keeps advancing that generator): reproducible under ``torch.manual_seed``, different for every optimizer built."""
+    if seed is None:
+        seed = int(torch.randint(0, 2**62, (1,)).item())
+    return int(seed) & (2**63 - 1)
 
 
 def _reference_noise(shape, clipped_normal: bool) -> torch.Tensor:
@@ -518,7 +546,7 @@ class CEMOptimizer(Optimizer):
         self.alpha = alpha
         self.return_mean_elites = return_mean_elites
         self._clipped_normal = clipped_normal
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.seed = _default_seed(seed)
         self.calls = 0
         # the reference's CEM is shape-generic (notebooks/cem_rosenbrock_ex.ipynb optimises a [2] vector):
         # kernels only see the flattened variable; [H, A] bounds keep their meaning for the fused plan path
@@ -541,25 +569,31 @@ class CEMOptimizer(Optimizer):
                  callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
         x0 = x0.to(device=self.device, dtype=torch.float32).contiguous()
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and x0.ndim == 2 and self.sampler == "philox") else None
-        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+        # a hipets objective that draws its randomness in-kernel: iteration i of this call samples AND rolls out with the
+        # counter-based streams (seed ^ objective seed, calls * iterations + i), whether the loop runs inside the library
+        # (one hipets_plan_cem call) or here (callback / injected noise / force_generic): both give the same numbers
+        fused = _fused_target(obj_fun) if (x0.ndim == 2 and self.sampler == "philox") else None
+        if fused is not None and fused.engine is not self.engine:
+            fused = None
+        seed = (self.seed ^ fused.seed) if fused is not None else self.seed
+        noise = kwargs.get("noise")  # optional injected z per iteration (parity tests)
+        if fused is not None and callback is None and noise is None and not kwargs.get("force_generic", False):
             _prepare_fused(fused, [self.population_size])
             return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
-                                        fused.num_particles, seed=self.seed ^ fused.seed, plan_id=self.calls)
+                                        fused.num_particles, seed=seed, plan_id=self.calls)
         p = self._params
         mu, dispersion = self._init_population_params(x0)
         mu, dispersion = mu.contiguous(), dispersion.contiguous()
         best_solution = torch.zeros_like(mu)
         best_value = torch.full((1,), -float("inf"), device=self.device, dtype=torch.float32)
         population = torch.empty((self.population_size,) + tuple(x0.shape), device=self.device, dtype=torch.float32)
-        noise = kwargs.get("noise")  # optional injected z per iteration (parity tests)
         for i in range(self.num_iterations):
+            stream = self.calls * self.num_iterations + i
             z = None if noise is None else noise[i].to(self.device, torch.float32).contiguous()
             if z is None and self.sampler == "torch":
                 z = _reference_noise(tuple(population.shape), self._clipped_normal).to(self.device).contiguous()
-            self.engine.cem_sample(p, mu, dispersion, self.lower_bound, self.upper_bound, population, z=z,
-                                   seed=self.seed, stream_id=self.calls * self.num_iterations + i)
-            values = obj_fun(population)
+            self.engine.cem_sample(p, mu, dispersion, self.lower_bound, self.upper_bound, population, z=z, seed=seed, stream_id=stream)
+            values = fused.evaluate_seeded(obj_fun.obs, population, seed, stream) if fused is not None else obj_fun(population)
             if callback is not None:
                 callback(population, values, i)
             if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
@@ -593,33 +627,37 @@ class MPPIOptimizer(Optimizer):
         self.beta = beta
         self.gamma = gamma
         self.refinements = num_iterations
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.seed = _default_seed(seed)
         self.calls = 0
 
     def optimize(self, obj_fun: Callable[[torch.Tensor], torch.Tensor], x0: Optional[torch.Tensor] = None,
                  callback: Optional[Callable[[torch.Tensor, torch.Tensor, int], None]] = None, **kwargs) -> torch.Tensor:
         H, A, pop = self.planning_horizon, self.action_dimension, self.population_size
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("noise") is None and self.sampler == "philox") else None
-        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+        fused = _fused_target(obj_fun) if self.sampler == "philox" else None  # see CEMOptimizer.optimize
+        if fused is not None and fused.engine is not self.engine:
+            fused = None
+        seed = (self.seed ^ fused.seed) if fused is not None else self.seed
+        noise = kwargs.get("noise")
+        if fused is not None and callback is None and noise is None and not kwargs.get("force_generic", False):
             _prepare_fused(fused, [pop])
             self.mean = self.mean.contiguous()
             self.engine.plan_mppi(pop, H, A, self.refinements, self.gamma, self.beta, self.mean, self.lower_bound, self.upper_bound,
-                                  obj_fun.obs, fused.num_particles, seed=self.seed ^ fused.seed, plan_id=self.calls)
+                                  obj_fun.obs, fused.num_particles, seed=seed, plan_id=self.calls)
             return self.mean.clone()
         shifted = self.mean.clone()
         shifted[:-1] = self.mean[1:]  # :258
         self.mean = shifted.contiguous()
         past_action = self.mean[0].clone()  # :257 (a view of the shifted tensor; constant across refinements)
         population = torch.empty((pop, H, A), device=self.device, dtype=torch.float32)
-        noise = kwargs.get("noise")
         for k in range(self.refinements):
+            stream = self.calls * self.refinements + k
             z = None if noise is None else noise[k].to(self.device, torch.float32).contiguous()
             if z is None and self.sampler == "torch":
                 z = _reference_noise((pop, H, A), False).to(self.device).contiguous()
             self.engine.mppi_sample(pop, H, A, self.beta, self.mean, past_action, self.lower_bound, self.upper_bound, population,
-                                    z=z, seed=self.seed, stream_id=self.calls * self.refinements + k)
-            values = obj_fun(population)
+                                    z=z, seed=seed, stream_id=stream)
+            values = fused.evaluate_seeded(obj_fun.obs, population, seed, stream) if fused is not None else obj_fun(population)
             if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
                 values = values.to(device=self.device, dtype=torch.float32).contiguous()
             if callback is not None:  # the reference calls back after the NaN filter here (:297-300)
@@ -665,7 +703,7 @@ class ICEMOptimizer(Optimizer):
         self.population_size_module = population_size_module
         if self.population_size_module:
             self.keep_elite_size = self._round_up_to_module(self.keep_elite_size, self.population_size_module)
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2**63 - 1)
+        self.seed = _default_seed(seed)
         self.calls = 0
 
     @staticmethod
@@ -687,8 +725,11 @@ class ICEMOptimizer(Optimizer):
         H, A = x0.shape
         K, keep = int(self.elite_num), int(self.keep_elite_size)
         self.calls += 1
-        fused = _fused_target(obj_fun) if (callback is None and kwargs.get("inject") is None and self.sampler == "philox") else None
-        if fused is not None and fused.engine is self.engine and not kwargs.get("force_generic", False):
+        fused = _fused_target(obj_fun) if self.sampler == "philox" else None  # see CEMOptimizer.optimize
+        if fused is not None and fused.engine is not self.engine:
+            fused = None
+        seed = (self.seed ^ fused.seed) if fused is not None else self.seed
+        if fused is not None and callback is None and kwargs.get("inject") is None and not kwargs.get("force_generic", False):
             sizes = []
             for i in range(self.num_iterations):
                 extra = 0
@@ -704,7 +745,7 @@ class ICEMOptimizer(Optimizer):
             has_elite = self.elite is not None
             elite = self.elite.contiguous() if has_elite else torch.empty((K, H, A), device=self.device, dtype=torch.float32)
             out = eng.plan_icem(p, x0, self.lower_bound, self.upper_bound, elite, has_elite, obj_fun.obs, fused.num_particles,
-                                seed=self.seed ^ fused.seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"))
+                                seed=seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"))
             if self.num_iterations > 0:
                 self.elite = elite
             return out
@@ -733,7 +774,7 @@ class ICEMOptimizer(Optimizer):
             if normals is not None:
                 normals = normals.to(self.device, torch.float32).contiguous()
             eng.icem_sample(n, H, A, self.colored_noise_exponent, mu, var, self.lower_bound, self.upper_bound, population,
-                            normals=normals, seed=self.seed, stream_id=sid)
+                            normals=normals, seed=seed, stream_id=sid)
             if self.elite is not None:
                 if "keep_perm" in inj:
                     perm = inj["keep_perm"].to(self.device)
@@ -744,13 +785,13 @@ class ICEMOptimizer(Optimizer):
                     en = inj.get("end_noise")
                     if en is not None:
                         en = en.to(self.device, torch.float32).contiguous()
-                    eng.icem_shift(kept.shape[0], H, A, kept, mu, var, population[n:], end_noise=en, seed=self.seed,
+                    eng.icem_shift(kept.shape[0], H, A, kept, mu, var, population[n:], end_noise=en, seed=seed,
                                    stream_id=sid + 1)
                 elif i == self.num_iterations - 1:  # :463-464
                     population[n:] = mu.unsqueeze(0)
                 else:  # :465-466
                     population[n:] = kept
-            values = obj_fun(population)
+            values = fused.evaluate_seeded(obj_fun.obs, population, seed, sid + 3) if fused is not None else obj_fun(population)
             if callback is not None:
                 callback(population, values, i)
             if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
@@ -778,21 +819,43 @@ _TARGET_ALIASES = {
 }
 
 
-def _cfg_get(cfg, key, default=None):
+def _cfg_to_dict(cfg) -> dict:
+    """Top-level keys of a plain dict or an OmegaConf ``DictConfig`` as a dict.  OmegaConf raises ``MissingMandatoryValue``
+    (not a KeyError) when a key that holds ``???`` is read -- and the stock configs ship ``lower_bound: ???``,
+    ``upper_bound: ???``, ``action_lb: ???``, ``action_ub: ???`` (conf/action_optimizer/*.yaml, conf/algorithm/pets.yaml)
+    -- so missing values are returned as the string "???" and filtered by the callers, like hydra's instantiate is fed by
+    the reference only after it has written the bounds into the config (trajectory_opt.py:525-527, core.py:101-106)."""
     try:
-        return cfg[key]
-    except (KeyError, TypeError, AttributeError):
-        return getattr(cfg, key, default)
+        from omegaconf import OmegaConf  # real OmegaConf: resolves interpolations too
+
+        if OmegaConf.is_config(cfg):
+            return dict(OmegaConf.to_container(cfg, resolve=True, throw_on_missing=False))
+    except ImportError:
+        pass
+    out = {}
+    for k in list(cfg.keys()):
+        try:
+            out[k] = cfg[k]
+        except Exception as exc:  # omegaconf.errors.MissingMandatoryValue of a DictConfig-like object
+            if type(exc).__name__ != "MissingMandatoryValue":
+                raise
+            out[k] = "???"
+    return out
+
+
+def _is_missing(v) -> bool:
+    return isinstance(v, str) and v == "???"
 
 
 def _instantiate(cfg, **overrides):
-    """hydra.utils.instantiate when hydra is present, else a minimal ``_target_`` resolver
-    (object construction only; the reference does exactly this at trajectory_opt.py:527,741)."""
-    kwargs = {k: cfg[k] for k in cfg.keys()}
+    """A minimal ``_target_`` resolver (object construction only; the reference does exactly this through
+    hydra.utils.instantiate at trajectory_opt.py:527,741).  Works on plain dicts and OmegaConf nodes; placeholders
+    ("???") that no override filled are dropped so the target's own defaults / errors apply."""
+    kwargs = _cfg_to_dict(cfg)
     kwargs.update(overrides)
     target = kwargs.pop("_target_")
     target = _TARGET_ALIASES.get(target, target)
-    kwargs = {k: v for k, v in kwargs.items() if not (isinstance(v, str) and v == "???")}
+    kwargs = {k: v for k, v in kwargs.items() if not _is_missing(v)}
     mod, _, name = target.rpartition(".")
     return getattr(importlib.import_module(mod), name)(**kwargs)
 
@@ -858,9 +921,17 @@ class TrajectoryOptimizerAgent(Agent):
 
     def reset(self, planning_horizon: Optional[int] = None):
         if planning_horizon:  # :644-651
+            old = self.optimizer.optimizer
             self.optimizer = TrajectoryOptimizer(self.optimizer_args["optimizer_cfg"], self.optimizer_args["action_lb"],
                                                  self.optimizer_args["action_ub"], planning_horizon=planning_horizon,
                                                  replan_freq=self.replan_freq)
+            # the rebuilt optimizer continues the old one's counter-based streams (same seed, call counter carried over)
+            # instead of replaying them from plan 1: the reference's global generator keeps advancing across resets too
+            new = self.optimizer.optimizer
+            if hasattr(old, "calls") and hasattr(new, "calls"):
+                new.calls = old.calls
+                if hasattr(old, "seed") and _cfg_to_dict(self.optimizer_args["optimizer_cfg"]).get("seed") is None:
+                    new.seed = old.seed
         self.optimizer.reset()
 
     def _require_eval_fn(self):
@@ -919,6 +990,8 @@ class BatchedCEMAgent(Agent):
         if self.engine.spec is not self.eval_fn.spec:
             self.engine.set_model(self.eval_fn.spec)
         self.eval_fn.check_batch(self._params.population_size)
+        if self.engine.plan_mode != "fast":
+            self.engine.set_plan_mode("fast")
         self.calls += 1
         best = self.engine.plan_cem(self._params, self.previous_solution, self.lower, self.upper, obs_batch,
                                     self.eval_fn.num_particles, seed=self.seed ^ self.eval_fn.seed, plan_id=self.calls,
@@ -935,17 +1008,12 @@ class BatchedCEMAgent(Agent):
 
 def complete_agent_cfg(env, agent_cfg):
     """The subset of mbrl/planning/core.py:71-123 a trajectory-optimizer agent config needs: fill
-    ``action_lb`` / ``action_ub`` placeholders ("???" or missing) from the action space."""
-    def missing(key):
-        try:
-            v = agent_cfg[key]
-        except (KeyError, AttributeError):
-            return key in getattr(agent_cfg, "keys", lambda: [])()
-        return isinstance(v, str) and v == "???"
-
-    if missing("action_lb"):
+    ``action_lb`` / ``action_ub`` placeholders ("???") from the action space.  Works on plain dicts and on
+    OmegaConf DictConfigs (whose "???" values raise MissingMandatoryValue when read)."""
+    have = _cfg_to_dict(agent_cfg)
+    if "action_lb" in have and _is_missing(have["action_lb"]):
         agent_cfg["action_lb"] = env.action_space.low.tolist()
-    if missing("action_ub"):
+    if "action_ub" in have and _is_missing(have["action_ub"]):
         agent_cfg["action_ub"] = env.action_space.high.tolist()
     return agent_cfg
 

@@ -52,6 +52,31 @@ def test_struct_layouts_match_header_field_order():
     assert fields("hipets_icem_params") == [f[0] for f in _lib.IcemParams._fields_]
     assert fields("hipets_planet_desc") == [f[0] for f in _lib.PlanetDesc._fields_]
     assert fields("hipets_planet_opts") == [f[0] for f in _lib.PlanetOpts._fields_]
+    assert fields("hipets_plan_trace") == [f[0] for f in _lib.PlanTrace._fields_]
+
+
+def test_integration_md_stub_matches_header_and_binding():
+    """The reference-side ctypes stub printed in INTEGRATION.md is executed as written: every Structure it defines must have
+    the header's field order and the binding's field types (a stale stub shifts every later field by 4 bytes)."""
+    from hipets import _lib
+
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if "class RolloutOpts" in b)
+    classes = re.findall(r"(class \w+\(C\.Structure\):.*?\n(?=\S|\Z))", stub, flags=re.S)
+    assert classes, "no ctypes Structure found in the INTEGRATION.md stub"
+    ns = {"C": ctypes}
+    for c in classes:
+        exec(c, ns)
+    by_header = {"RolloutOpts": _lib.RolloutOpts, "ModelDesc": _lib.ModelDesc, "CemParams": _lib.CemParams,
+                 "IcemParams": _lib.IcemParams, "PlanTrace": _lib.PlanTrace}
+    checked = 0
+    for name, ref in by_header.items():
+        if name in ns:
+            assert [(f[0], f[1]) for f in ns[name]._fields_] == [(f[0], f[1]) for f in ref._fields_], name
+            assert ctypes.sizeof(ns[name]) == ctypes.sizeof(ref)
+            checked += 1
+    assert checked >= 1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
