@@ -8,16 +8,23 @@ TrajectoryOptimizerAgent.act does per environment step, on BASELINE.json configs
 Inputs (weights, s0, bounds) are resident in HBM before the timed region; synthetic random-init
 weights (reference initialiser), fp32 arithmetic end to end (fp64 input normaliser like the reference).
 
-    python bench.py [--gpus N --steps K --warmup W]        # N>1: launched by torch.distributed.run
+    python bench.py [--gpus N --steps K --warmup W] [--mode device|fast]     # N>1: launched by torch.distributed.run
 
-N>1: candidates sharded over N ranks (one process per GPU), replicated sampling, one RCCL all-gather of the candidate
-returns per CEM iteration.  Default `--scaling weak` keeps cfg2's pop 500 PER RANK (pop 500 N in total); the literal
-configs[2] (the same pop-500 plan sharded N ways, latency-bound by construction) is timed too and
-reported as the extra `cfg3_strong` block; `--scaling strong` makes it the headline value instead.
+--mode (randomness of the rollouts inside the fused plan):
+  device  the reference's propagation semantics: ONE balanced permutation of all 10 000 rows per step, iid eps, drawn
+          in-kernel; one rollout-kernel launch per step (rows change workgroups every step).  THE HEADLINE.
+  fast    one launch per rollout, block-balanced member schedule (reported as the `fast_mode` block of the same line).
+
+N>1 (BASELINE.json configs[2]): the SAME pop-500 plan with its candidates sharded over N ranks (one process per GPU,
+"scaling": "strong"), driven by the library itself (hipets_plan_cem_sharded: replicated sampling, local rollouts, ONE
+RCCL all-gather of the pop returns per CEM iteration, identical refit on every rank).  `--scaling weak` keeps 500 candidates
+per rank instead (pop 500 N).  If the RCCL communicator cannot be created the ranks fall back to independent single-GPU
+plans and say so in the line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -65,14 +72,23 @@ def _usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(budget_s=20.0):
-    """The reference's algorithm on this box's host cores: the oracle (a torch-CPU restatement that is bitwise
-    equal to mbrl-lib's ModelEnv + CEMOptimizer, see oracle/) timed on a BOUNDED sample of the cfg2 workload.
-    Checker code, used here ONLY as the reported baseline, never by the product path.
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
-    The per-step cost of evaluate_action_sequences does not depend on the step index, so the sample is cfg2's
-    full batch (pop 500 x 20 particles) rolled for a shortened horizon sized to fit the time budget; the thread
-    count is calibrated first (torch's default of one thread per logical core can be catastrophically slow)."""
+
+def cpu_baseline(budget_s=30.0):
+    """The reference's algorithm on this box's host cores: the oracle -- a torch-CPU restatement
+    that is BITWISE equal to mbrl-lib's TrajectoryOptimizerAgent + CEMOptimizer + ModelEnv at this exact size
+    (tests/test_oracle_full_size.py pins it against a golden recorded from the unmodified reference) -- timed on FULL
+    cfg2 plans: one warm-up plan, then >= 5 timed plans (CEM loop included), min and median reported.  Checker code, used
+    here ONLY as the reported baseline, never by the product path.  The thread count is calibrated first (torch's
+    default of one thread per logical core can be catastrophically slow on a many-core host)."""
     from oracle import pets_oracle as po
 
     om = po.make_synthetic_model(OBS, ACT, ensemble_size=ENSEMBLE, hid=HID, num_layers=LAYERS, seed=0, nontrivial_stats=False)
@@ -80,11 +96,18 @@ def cpu_baseline(budget_s=20.0):
     gen = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
+    lb, ub = -torch.ones(HORIZON, ACT), torch.ones(HORIZON, ACT)
 
-    def run(h):
-        acts = torch.rand(POP, h, ACT, generator=g) * 2 - 1
+    def one_step_batch():
+        acts = torch.rand(POP, 1, ACT, generator=g) * 2 - 1
         t0 = time.perf_counter()
         po.rollout(om, acts, s0, PARTICLES, global_rng=True, generator=gen)
+        return time.perf_counter() - t0
+
+    def plan():
+        obj = lambda pop_: po.rollout(om, pop_, s0, PARTICLES, global_rng=True, generator=gen)  # noqa: E731
+        t0 = time.perf_counter()
+        po.cem_optimize(obj, torch.zeros(HORIZON, ACT), lb, ub, ITERS, ELITE_RATIO, POP, ALPHA, return_mean_elites=True)
         return time.perf_counter() - t0
 
     t_start = time.perf_counter()
@@ -92,24 +115,30 @@ def cpu_baseline(budget_s=20.0):
     best_threads, best_t = 1, None
     for nt in sorted({1, min(8, usable), min(16, usable), min(32, usable), min(64, usable)}):
         torch.set_num_threads(nt)
-        run(1)  # warm-up for this thread count
-        t = min(run(1), run(1))
+        one_step_batch()  # warm-up for this thread count
+        t = min(one_step_batch(), one_step_batch(), one_step_batch())
         if best_t is None or t < best_t:
             best_threads, best_t = nt, t
-        if time.perf_counter() - t_start > 0.4 * budget_s:
+        if time.perf_counter() - t_start > 0.2 * budget_s:
             break
     torch.set_num_threads(best_threads)
-    remaining = max(1.0, budget_s - (time.perf_counter() - t_start))
-    h = int(max(1, min(HORIZON, remaining / 2 / best_t)))
-    reps = int(max(2, min(6, remaining / (h * best_t))))
-    times = [run(h) for _ in range(reps)]
-    cs = POP * PARTICLES * h
-    v = cs / min(times)
-    return {"value": v, "unit": "candidate-steps/s", "cores": best_threads, "kind": "port",
-            "sample": f"{reps} x evaluate_action_sequences on cfg2's batch (pop {POP} x {PARTICLES} particles) for {h} of {HORIZON} "
-                      f"horizon steps ({cs} candidate-steps), min time; thread count calibrated over <= {usable} usable "
-                      f"cores; torch {torch.__version__} CPU",
-            "plans_per_s_extrapolated": v / (ITERS * POP * PARTICLES * HORIZON)}
+    plan()  # warm-up plan
+    times = []
+    while len(times) < 5 or (time.perf_counter() - t_start < budget_s and len(times) < 12):
+        times.append(plan())
+        if len(times) >= 5 and time.perf_counter() - t_start > budget_s:
+            break
+    cs = ITERS * POP * PARTICLES * HORIZON
+    return {"value": cs / min(times), "unit": "candidate-steps/s", "cores": best_threads, "kind": "port",
+            "value_median": cs / statistics.median(times), "ms_per_plan_min": 1e3 * min(times),
+            "ms_per_plan_median": 1e3 * statistics.median(times), "plans_timed": len(times),
+            "sample": f"{len(times)} full cfg2 plans (CEM x {ITERS} iterations x pop {POP} x {PARTICLES} particles x H {HORIZON} = {cs} "
+                      f"candidate-steps each) after 1 warm-up plan; min time -> value, median -> value_median; threads calibrated over "
+                      f"<= {usable} usable cores",
+            "host": {"nproc": os.cpu_count(), "usable_cores": usable, "cpu_model": _cpu_model(), "torch": torch.__version__,
+                     "parallel_info": " | ".join(ln.strip() for ln in torch.__config__.parallel_info().splitlines()
+                                                 if any(k in ln for k in ("threads", "OpenMP", "MKL")))[:400]},
+            "plans_per_s": 1.0 / min(times)}
 
 
 def torch_rocm_port(device, plans=2):
@@ -147,10 +176,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
+    ap.add_argument("--mode", choices=["device", "fast"], default="device", help="randomness mode of the HEADLINE plan")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched", action="store_true", help="skip the extra batched-planning measurement")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-extras", "--no-batched", dest="no_extras", action="store_true", help="skip the extra blocks (other mode, batched planning, agent.act)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
 
     import hipets
@@ -167,6 +197,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -178,63 +209,136 @@ def main():
 
     engine = hipets.get_engine(device)
     spec = synthetic_spec(device)
-    eval_fn = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0)
     lb, ub = [[-1.0] * ACT] * HORIZON, [[1.0] * ACT] * HORIZON
     s0 = (np.random.default_rng(0).standard_normal(OBS) * 0.1).astype(np.float32)
     x0 = torch.zeros(HORIZON, ACT, device=device)
+    flops_cs = spec.flops_per_candidate_step()
+
+    # ---- N > 1: how the sharded plan is driven -------------------------------------------------------------------------
+    comm_info = {}
+    sharded = "single"
     if world > 1:
-        objective = _BoundObjective(hdist.ShardedEvalFn(eval_fn), s0)  # generic path + one all-gather per iteration
-    else:
-        objective = _BoundObjective(eval_fn, s0)  # fused hipets_plan_cem
+        if backend == "nccl":
+            try:
+                hdist.init_engine_comm(engine)  # the library's own RCCL communicator; torch.distributed only carried the id
+                sharded = "library"
+            except Exception as exc:  # SURVEY.md section 5 "failure detection": RCCL error -> single-GPU plans + a report
+                sharded = "fallback"
+                comm_info["fallback_reason"] = f"hipets_comm_init failed: {str(exc)[:200]}"
+                print(f"[bench rank {rank}] RCCL communicator unavailable, falling back to independent single-GPU plans: {exc}", file=sys.stderr)
+            flags = torch.tensor([1 if sharded == "library" else 0], device=device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)  # all ranks take the same path
+            if int(flags.item()) == 0 and sharded == "library":
+                sharded = "fallback"
+                comm_info["fallback_reason"] = "another rank failed to join the communicator"
+            try:
+                comm_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        else:
+            sharded = "torch.distributed"  # gloo: several ranks on one GPU, per-iteration all-gather through the host
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
-
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(pop_total, steps, warmup):
-        """warmup untimed plans, then exactly `steps` plans between barrier+synchronize; max over ranks."""
+    def run(mode, pop_total, steps, warmup):
+        """`warmup` untimed plans, then exactly `steps` plans between barrier + synchronize; MAX over ranks.
+        Returns (seconds, rollout-kernel launches, summed kernel ms)."""
+        eval_fn = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode=mode)
         opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop_total, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
+        if sharded == "library":
+            engine.set_plan_mode(mode)
+            counter = {"n": 0}
+
+            def plan():
+                counter["n"] += 1
+                return engine.plan_cem_sharded(opt._params, x0, opt.lower_bound, opt.upper_bound, s0, PARTICLES, seed=0, plan_id=counter["n"])
+        elif sharded == "torch.distributed":
+            objective = _BoundObjective(hdist.ShardedEvalFn(eval_fn), s0)  # generic path + one all-gather per iteration
+            plan = lambda: opt.optimize(objective, x0=x0)  # noqa: E731
+        else:
+            objective = _BoundObjective(eval_fn, s0)  # fused hipets_plan_cem
+            plan = lambda: opt.optimize(objective, x0=x0)  # noqa: E731
         for _ in range(warmup):
-            opt.optimize(objective, x0=x0)
+            plan()
         engine.timing_enable(True)
         engine.timing_read(reset=True)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            sol = opt.optimize(objective, x0=x0)
+            sol = plan()
         barrier()
         el = time.perf_counter() - t0
         launches_, kernel_ms_ = engine.timing_read(reset=True)
         engine.timing_enable(False)
         if world > 1:
-            import torch.distributed as dist
-
             t = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         assert torch.isfinite(sol).all()
         return el, launches_, kernel_ms_
 
-    # N = 1: BASELINE.json configs[1] (pop 500).  N > 1: per-GPU work fixed (pop 500 per rank, sharded evaluation, one
-    # all-gather of returns per iteration) = "weak"; --scaling strong times configs[2] literally (the SAME pop-500 plan
-    # sharded N ways), which is also always reported as the extra `cfg3_strong` block of the N > 1 line.
-    pop = POP * world if (world > 1 and args.scaling == "weak") else POP
-    elapsed, launches, kernel_ms = run(pop, args.steps, args.warmup)
-    extra = None
-    if world > 1 and args.scaling == "weak":
-        e2, _, _ = run(POP, args.steps, max(1, args.warmup // 2))
-        extra = {"workload": f"configs[2]: the pop={POP} plan sharded over {world} ranks (strong scaling)", "value": args.steps * ITERS * POP *
-                 PARTICLES * HORIZON / e2, "unit": "candidate-steps/s", "ms_per_step": 1e3 * e2 / args.steps, "plans_per_s": args.steps / e2}
+    def roofline_block(mode, pop_total, launches, kernel_ms):
+        """Dominant kernel = hipets::rollout_kernel.  DEVICE mode: one launch = ONE step of the local rows; FAST mode: one
+        launch = the whole horizon.  achieved = algorithmic FLOP of a launch / its average duration (hipEvents riding on
+        every dispatch packet of the timed region, on the launch stream)."""
+        local_pop = -(-pop_total // world) if (world > 1 and sharded != "fallback") else pop_total  # largest shard
+        steps_per_launch = 1 if mode == "device" else HORIZON
+        alg = flops_cs * local_pop * PARTICLES * steps_per_launch
+        avg_s = (kernel_ms / max(launches, 1)) * 1e-3
+        ach = alg / avg_s / 1e12 if launches else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"rollout_kernel_bytes_per_launch_{mode}")
+            except Exception:
+                traffic = None
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_FP32_TFLOPS) if ach else None,
+                "traffic": traffic, "kernel": "hipets::rollout_kernel", "launches": launches, "avg_launch_ms": 1e3 * avg_s if launches else None,
+                "algorithmic_flops_per_launch": alg, "flops_per_candidate_step": flops_cs,
+                "launch_covers": f"{local_pop} candidates x {PARTICLES} particles x {steps_per_launch} step(s)",
+                "kernel_time_share_of_plan": None}
 
-    # extra (N = 1 only, outside the timed region above): batched planning, 8 cfg2 environments per launch -- the same
-    # kernels with all 256 CUs busy (a single cfg2 plan has 2.4 row tiles per CU).  Reported, never the headline value.
-    batched = None
-    if world == 1 and not args.no_batched:
+    # N = 1: BASELINE.json configs[1].  N > 1: configs[2] = the SAME pop-500 plan sharded ("strong"); --scaling weak keeps pop 500 / rank
+    pop = POP * world if (world > 1 and args.scaling == "weak") else POP
+    elapsed, launches, kernel_ms = run(args.mode, pop, args.steps, args.warmup)
+    roof = roofline_block(args.mode, pop, launches, kernel_ms)
+    roof["kernel_time_share_of_plan"] = (kernel_ms * 1e-3) / elapsed if elapsed > 0 else None
+    extras = {}
+    other = "fast" if args.mode == "device" else "device"
+    if not args.no_extras:
+        n_other = max(3, args.steps // 3)
+        e2, l2, k2 = run(other, pop, n_other, 2)
+        r2 = roofline_block(other, pop, l2, k2)
+        extras[f"{other}_mode"] = {"workload": f"the same plan with mode='{other}' rollouts", "value": n_other * ITERS * pop * PARTICLES * HORIZON / e2,
+                                   "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e2 / n_other, "roofline": r2}
+    if world > 1 and not args.no_extras:
+        alt_pop = POP if args.scaling == "weak" else POP * world
+        n_alt = max(3, args.steps // 3)
+        e3, _, _ = run(args.mode, alt_pop, n_alt, 2)
+        extras["weak_scaling" if args.scaling == "strong" else "cfg3_strong"] = {
+            "workload": f"pop {alt_pop} in total ({alt_pop // world} per rank) sharded over {world} ranks", "value": n_alt * ITERS * alt_pop * PARTICLES * HORIZON / e3,
+            "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e3 / n_alt}
+        if sharded in ("library", "torch.distributed"):  # what one all-gather of the returns costs on this fabric
+            buf_in = torch.zeros(-(-POP // world), device=device if backend == "nccl" else "cpu")
+            buf_out = torch.zeros(world * buf_in.numel(), device=buf_in.device)
+            for _ in range(5):
+                dist.all_gather_into_tensor(buf_out, buf_in) if backend == "nccl" else dist.all_gather(list(buf_out.view(world, -1).unbind(0)), buf_in)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dist.all_gather_into_tensor(buf_out, buf_in) if backend == "nccl" else dist.all_gather(list(buf_out.view(world, -1).unbind(0)), buf_in)
+            barrier()
+            comm_info["allgather_us_per_iteration"] = 1e6 * (time.perf_counter() - t0) / 50
+
+    if world == 1 and not args.no_extras:
+        eval_fast = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode="fast")
+        # batched planning: 8 cfg2 environments per launch -- the same kernels with all 256 CUs busy.  Never the headline.
         n_env = 8
-        agent = hipets.BatchedCEMAgent(eval_fn, n_env, [-1.0] * ACT, [1.0] * ACT, HORIZON, ITERS, ELITE_RATIO, POP, ALPHA, seed=0)
+        agent = hipets.BatchedCEMAgent(eval_fast, n_env, [-1.0] * ACT, [1.0] * ACT, HORIZON, ITERS, ELITE_RATIO, POP, ALPHA, seed=0)
         s0b = (np.random.default_rng(0).standard_normal((n_env, OBS)) * 0.1).astype(np.float32)
         for _ in range(2):
             agent.plan(s0b)
@@ -249,90 +353,57 @@ def main():
         eb = time.perf_counter() - t0
         lb_, kms_ = engine.timing_read(reset=True)
         engine.timing_enable(False)
-        tf = spec.flops_per_candidate_step() * n_env * POP * PARTICLES * HORIZON / (kms_ / max(lb_, 1) * 1e-3) / 1e12
-        batched = {"workload": f"{n_env} x configs[1] environments planned in one set of launches (hipets_plan_cem_batched)",
-                   "value": nb * n_env * ITERS * POP * PARTICLES * HORIZON / eb, "unit": "candidate-steps/s",
-                   "ms_per_env_plan": 1e3 * eb / nb / n_env, "rollout_kernel_tflops": tf, "rollout_kernel_frac_of_fp32_peak": tf / PEAK_FP32_TFLOPS}
-
-    # extra (N = 1): the same plan with the reference's EXACT propagation semantics (one global balanced random
-    # permutation of all 10 000 rows per step, per-step launches, state through HBM) instead of FAST mode's
-    # block-balanced schedule -- shows what the fast mode's restructuring is worth and that it is not needed for speed-up.
-    exact_sem = None
-    if world == 1 and not args.no_batched:
-        fn_x = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode="exact_device")
-        opt_x = hipets.CEMOptimizer(ITERS, ELITE_RATIO, POP, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
-        obj_x = _BoundObjective(fn_x, s0)
-        for _ in range(2):
-            opt_x.optimize(obj_x, x0=x0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nx = max(2, args.steps // 5)
-        for _ in range(nx):
-            opt_x.optimize(obj_x, x0=x0)
-        torch.cuda.synchronize()
-        ex = time.perf_counter() - t0
-        exact_sem = {"workload": "configs[1] with mode='exact_device': reference TS1 semantics (global randperm per step), device RNG",
-                     "value": nx * ITERS * POP * PARTICLES * HORIZON / ex, "unit": "candidate-steps/s", "ms_per_plan": 1e3 * ex / nx}
-
-    # extra (N = 1 only): the whole drop-in call, TrajectoryOptimizerAgent.act(obs) -> np.ndarray[A]: observation from host
-    # memory, plan on the device, ONE D2H of the plan, warm-start shift (what a control loop pays per environment step)
-    agent_act = None
-    if world == 1 and not args.no_batched:
+        tf = flops_cs * n_env * POP * PARTICLES * HORIZON / (kms_ / max(lb_, 1) * 1e-3) / 1e12
+        extras["batched_planning"] = {"workload": f"{n_env} x configs[1] environments planned in one set of launches (hipets_plan_cem_batched, FAST mode)",
+                                      "value": nb * n_env * ITERS * POP * PARTICLES * HORIZON / eb, "unit": "candidate-steps/s",
+                                      "ms_per_env_plan": 1e3 * eb / nb / n_env, "rollout_kernel_tflops": tf,
+                                      "rollout_kernel_frac_of_fp32_peak": tf / PEAK_FP32_TFLOPS}
+        # the whole drop-in call, TrajectoryOptimizerAgent.act(obs) -> np.ndarray[A]: host observation in, plan on the device,
+        # ONE D2H of the plan, warm-start shift (what a control loop pays per environment step); same mode as the headline
         cfg = dict(_target_="hipets.CEMOptimizer", num_iterations=ITERS, elite_ratio=ELITE_RATIO, population_size=POP, alpha=ALPHA,
                    device=device, lower_bound="???", upper_bound="???", return_mean_elites=True, seed=0)
-        agent = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * ACT, [1.0] * ACT, planning_horizon=HORIZON)
-        agent.set_trajectory_eval_fn(eval_fn)
+        ag = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * ACT, [1.0] * ACT, planning_horizon=HORIZON)
+        ag.set_trajectory_eval_fn(hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode=args.mode))
         for _ in range(3):
-            agent.act(s0)
+            ag.act(s0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         na = max(5, args.steps // 2)
         for _ in range(na):
-            agent.act(s0)
+            ag.act(s0)
         ea = time.perf_counter() - t0  # act() returns host data: it is synchronous by construction
-        agent_act = {"workload": "hipets.TrajectoryOptimizerAgent.act(obs) on configs[1], host observation in, host action out",
-                     "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea}
+        extras["agent_act"] = {"workload": f"hipets.TrajectoryOptimizerAgent.act(obs) on configs[1] (mode='{args.mode}'), host observation in, host action out",
+                               "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea}
 
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
-    value = args.steps * cand_steps_per_plan / elapsed
-    flops_cs = spec.flops_per_candidate_step()
-    # dominant kernel = rollout_kernel: one launch rolls (pop / world) candidates x P particles x H steps
-    local_pop = -(-pop // world) if world > 1 else pop  # largest shard
-    alg_flops_per_launch = flops_cs * local_pop * PARTICLES * HORIZON
-    avg_launch_s = (kernel_ms / max(launches, 1)) * 1e-3
-    achieved = alg_flops_per_launch / avg_launch_s / 1e12 if launches else None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("rollout_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
+    plans_done = args.steps * (world if sharded == "fallback" else 1)  # fallback: every rank planned on its own
+    value = plans_done * cand_steps_per_plan / elapsed
+    mode_text = {"device": "DEVICE (reference TS1 semantics: one balanced permutation of all rows per step + iid eps, drawn in-kernel; one launch per step)",
+                 "fast": "FAST (in-kernel Philox, block-balanced TS1, one launch per rollout)"}[args.mode]
+    if world == 1:
+        workload = ("BASELINE.json configs[1]: PETS HalfCheetah obs=17 act=6, GaussianMLP ensemble=5 (4x200 SiLU, TS1), "
+                    f"CEM pop={pop} horizon={HORIZON} particles={PARTICLES} iters={ITERS}; one step = one plan (TrajectoryOptimizerAgent.act)")
+    elif args.scaling == "strong":
+        workload = (f"BASELINE.json configs[2]: the configs[1] plan (CEM pop={pop} horizon={HORIZON} particles={PARTICLES} iters={ITERS}, ensemble=5) "
+                    f"with its population sharded across {world} GPUs, one RCCL all-gather of the returns per CEM iteration")
+    else:
+        workload = (f"configs[1] scaled weakly: pop {pop} = {POP} per rank over {world} GPUs (configs[2] is the `cfg3_strong` block)")
     out = {
         "metric": "candidate-steps/sec (pop x particles x horizon / plan) per CEM iter; plans/sec",
         "value": value, "unit": "candidate-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: PETS HalfCheetah obs=17 act=6, GaussianMLP ensemble=5 (4x200 SiLU, TS1), "
-                               f"CEM pop={pop} horizon={HORIZON} particles={PARTICLES} iters={ITERS}; one step = one plan "
-                               "(TrajectoryOptimizerAgent.act)",
-                   "candidate_steps_per_plan": cand_steps_per_plan, "plans_per_s": args.steps / elapsed,
-                   "parallelism": f"population-sharded x{world}" if world > 1 else "single GPU, fused plan",
-                   "mode": "FAST (in-kernel Philox, block-balanced TS1)"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / PEAK_FP32_TFLOPS) if achieved else None, "traffic": traffic,
-                     "kernel": "hipets::rollout_kernel", "launches": launches,
-                     "avg_launch_ms": 1e3 * avg_launch_s if launches else None,
-                     "algorithmic_flops_per_launch": alg_flops_per_launch, "flops_per_candidate_step": flops_cs},
+        "config": {"workload": workload, "candidate_steps_per_plan": cand_steps_per_plan, "plans_per_s": plans_done / elapsed,
+                   "parallelism": {"single": "single GPU, fused plan (hipets_plan_cem)",
+                                   "library": f"population-sharded x{world}, in-library RCCL (hipets_plan_cem_sharded)",
+                                   "torch.distributed": f"population-sharded x{world}, torch.distributed {backend} all-gather per iteration",
+                                   "fallback": f"FALLBACK: {world} independent single-GPU plans (no communicator)"}[sharded],
+                   "mode": mode_text},
+        "roofline": roof,
     }
-    if extra is not None:
-        out["cfg3_strong"] = extra
-    if batched is not None:
-        out["batched_planning"] = batched
-    if exact_sem is not None:
-        out["exact_semantics"] = exact_sem
-    if agent_act is not None:
-        out["agent_act"] = agent_act
+    if comm_info:
+        out["comm"] = comm_info
+    out.update(extras)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
@@ -343,8 +414,6 @@ def main():
                 out["torch_rocm_port"] = {"error": str(exc)[:200]}
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
-
         dist.destroy_process_group()
 
 

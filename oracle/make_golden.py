@@ -306,8 +306,71 @@ def gen_agent_act(name, obs, act, mkw, pop, P, H, iters, n_steps=2, optimizer="c
     print(f"agent_{name}: actions {np.stack(actions).round(4).tolist()}")
 
 
+FULL_CASES = {
+    # BASELINE.json configs at their FULL sizes (SURVEY.md section 8 shorthand).  Only seeds and outputs are stored: the
+    # model is rebuilt from its seed by po.make_synthetic_model (a checksum of the weights guards that), the draws are the
+    # reference's own under torch.manual_seed / the ModelEnv generator.
+    "cfg2_cem": dict(obs=17, act=6, mkw=dict(ensemble_size=5, hid=200, seed=30), pop=500, P=20, H=30, iters=5, optimizer="cem"),
+    "cfg4_icem": dict(obs=45, act=17, mkw=dict(ensemble_size=7, hid=200, seed=31, elite=[0, 1, 2, 3, 4], termination="humanoid"),
+                      pop=1000, P=20, H=40, iters=5, optimizer="icem", module=7),
+    "cfg5_mppi": dict(obs=17, act=6, mkw=dict(ensemble_size=5, hid=200, seed=32), pop=2000, P=20, H=50, iters=5, optimizer="mppi"),
+}
+
+
+def weights_checksum(om) -> list:
+    return [float(w.double().abs().sum()) for w in om.weights]
+
+
+def full_case_agent_cfg(c, target_prefix, device, **extra):
+    """Optimizer config of a FULL_CASES entry (conf/action_optimizer/{cem,icem,mppi}.yaml with the PETS overrides)."""
+    if c["optimizer"] == "icem":
+        cfg = dict(_target_=f"{target_prefix}.ICEMOptimizer", num_iterations=c["iters"], elite_ratio=0.1, population_size=c["pop"],
+                   population_decay_factor=1.3, colored_noise_exponent=2.0, keep_elite_frac=0.3, alpha=0.1, device=device,
+                   lower_bound="???", upper_bound="???", return_mean_elites=True, population_size_module=c.get("module"))
+    elif c["optimizer"] == "mppi":
+        cfg = dict(_target_=f"{target_prefix}.MPPIOptimizer", num_iterations=c["iters"], population_size=c["pop"], gamma=0.9,
+                   sigma=1.0, beta=0.9, device=device, lower_bound="???", upper_bound="???")
+    else:
+        cfg = dict(_target_=f"{target_prefix}.CEMOptimizer", num_iterations=c["iters"], elite_ratio=0.1, population_size=c["pop"],
+                   alpha=0.1, device=device, lower_bound="???", upper_bound="???", return_mean_elites=True, clipped_normal=False)
+    cfg.update(extra)
+    return cfg
+
+
+def gen_agent_full(name, n_steps=2):
+    """A FULL_CASES config through the UNMODIFIED reference agent + ModelEnv on CPU under fixed seeds: consecutive act() calls
+    (the second call uses the shifted warm start and, for iCEM / MPPI, the persistent elites / mean)."""
+    mbrl = import_reference()
+    import omegaconf
+
+    c = FULL_CASES[name]
+    obs, act, P, H = c["obs"], c["act"], c["P"], c["H"]
+    om = po.make_synthetic_model(obs, act, **c["mkw"])
+    gen = torch.Generator().manual_seed(21)
+    me, _, _ = build_reference_model_env(om, obs, act, generator=gen)
+    cfg = omegaconf.OmegaConf.create(full_case_agent_cfg(c, "mbrl.planning", "cpu"))
+    agent = mbrl.planning.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H, replan_freq=1)
+    agent.set_trajectory_eval_fn(lambda s, a: me.evaluate_action_sequences(a, initial_state=s, num_particles=P))
+    observations = (np.random.default_rng(8).standard_normal((n_steps, obs)) * 0.1).astype(np.float32)
+    if om.termination == "humanoid":
+        observations[:, 0] = 1.4  # inside the healthy z range (termination_fns.py:88-95) so that plans matter
+    torch.manual_seed(4321)
+    actions, plans = [], []
+    for t in range(n_steps):
+        actions.append(np.asarray(agent.act(observations[t]), np.float32))
+        plans.append(agent.optimizer.previous_solution.numpy().copy())
+    meta = dict(kind="agent_full", name=name, torch_seed=4321, generator_seed=21, weights_checksum=weights_checksum(om))
+    _save_npz(f"agentfull_{name}.npz", meta, dict(observations=observations, actions=np.stack(actions), shifted_plans=np.stack(plans)))
+    print(f"agentfull_{name}: actions[0][:3]={np.stack(actions)[0][:3].round(4).tolist()}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--full-only" in sys.argv:
+        torch.set_num_threads(8)
+        for name in FULL_CASES:
+            gen_agent_full(name)
+        return
     torch.set_num_threads(4)
     for name, (obs, act, mkw, pop, P, H) in ROLLOUT_CASES.items():
         gen_rollout(name, obs, act, mkw, pop, P, H)
@@ -321,6 +384,8 @@ def main():
     gen_agent_act("icem_two_steps", 17, 6, dict(ensemble_size=5, hid=48, seed=23), pop=60, P=5, H=8, iters=3, optimizer="icem")
     gen_planet("cheetah_shape", 30, 6, 200, 200, pop=40, P=1, H=12, seed=1)   # conf/dynamics_model/planet.yaml sizes
     gen_planet("small_particles", 10, 3, 40, 24, pop=11, P=3, H=5, seed=2)
+    for name in FULL_CASES:
+        gen_agent_full(name)
 
 
 if __name__ == "__main__":

@@ -489,14 +489,20 @@ def cem_optimize(
     clipped_normal: bool = False,
     noise: Optional[Sequence[torch.Tensor]] = None,  # per-iteration z [pop,H,A] (already truncated / randn)
     record: Optional[list] = None,
+    teacher: Optional[Sequence[tuple]] = None,  # teacher[i] = (mu, dispersion) to START iteration i + 1 from (replay aid)
 ) -> torch.Tensor:
-    """CEMOptimizer.optimize (trajectory_opt.py:142-188) with :100-140 inlined."""
+    """CEMOptimizer.optimize (trajectory_opt.py:142-188) with :100-140 inlined.
+
+    ``teacher`` (never used by the pinned-to-reference paths) re-bases every iteration on another implementation's
+    recorded state, so a replay checks each iteration on its own instead of compounding a legitimate elite tie."""
     K = elite_count(population_size, elite_ratio)
     mu = x0.clone()
     disp = torch.ones_like(mu) if clipped_normal else ((upper - lower) ** 2) / 16  # :103-108
     best = torch.empty_like(mu)
     best_val = -np.inf
     for i in range(num_iterations):
+        if teacher is not None and i > 0:
+            mu, disp = teacher[i - 1][0].clone(), teacher[i - 1][1].clone()
         if noise is not None:
             z = noise[i]
         elif clipped_normal:
@@ -609,6 +615,7 @@ def icem_optimize(
     colored_noise_exponent: float, keep_elite_frac: float, alpha: float,
     return_mean_elites: bool = False, population_size_module: Optional[int] = None,
     inject: Optional[Sequence[dict]] = None, record: Optional[list] = None,
+    teacher: Optional[Sequence[tuple]] = None,  # teacher[i] = (mu, var, elite) to START iteration i + 1 from (replay aid)
 ) -> torch.Tensor:
     """ICEMOptimizer.optimize (trajectory_opt.py:391-487).  ``inject[i]`` may carry
     ``noise`` [n_i,H,A] (coloured, unit variance, already transposed), ``keep_perm`` [K] and
@@ -621,6 +628,9 @@ def icem_optimize(
     best = torch.empty_like(mu)
     best_val = -np.inf
     for i in range(num_iterations):
+        if teacher is not None and i > 0:
+            mu, var = teacher[i - 1][0].clone(), teacher[i - 1][1].clone()
+            state.elite = teacher[i - 1][2].clone()
         n = sizes[i]
         inj = inject[i] if inject is not None else {}
         rec_i = {}

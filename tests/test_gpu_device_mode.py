@@ -1,0 +1,119 @@
+"""DEVICE mode: the reference's TS1 / TS-infinity propagation semantics (ONE balanced permutation of all pop x particles rows
+per step, gaussian_mlp.py:203-205; iid eps, model.py:471-473) with the draws made in-kernel.  The kernel's own
+permutations and normals are exported through the ABI (hipets_device_perms, hipets_fast_normals) and the rollout is
+replayed through the oracle with the reference's `perms=` / `eps=` inputs -- exact arithmetic parity, tolerance T2."""
+import numpy as np
+import pytest
+import torch
+
+import hipets
+from conftest import to_spec
+from oracle import feistel_perm as fp
+from oracle import pets_oracle as po
+from test_gpu_rollout import SIZES, _random_case, assert_returns_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B", [5, 500, 2500, 10000, 20720, 40000])
+def test_exported_permutations_equal_the_cpu_restatement(engine, B):
+    om = po.make_synthetic_model(6, 2, ensemble_size=5, hid=16, seed=0)
+    engine.set_model(to_spec(om, 6, 2))
+    H = 3
+    perms = engine.device_perms(H, B, seed=99, stream_id=12).cpu().numpy()
+    assert perms.shape == (H, B)
+    for t in range(H):
+        assert np.array_equal(perms[t], fp.permutation(B, 99, 12, t))
+        assert np.unique(perms[t]).size == B
+
+
+@pytest.mark.parametrize("case", SIZES[:10], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_device_mode_replayed_through_oracle(engine, case):
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    seed, sid = 4321, 5
+    out = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid)
+    perms = None
+    if om.propagation != "expectation":
+        perms = engine.device_perms(H, pop * P, seed, sid).cpu()
+        assert tuple(perms.shape) == ((pop * P,) if om.propagation == "fixed_model" else (H, pop * P))
+    eps = None if om.deterministic else engine.fast_normals(H, pop * P, seed, sid).cpu()
+    ref = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    assert_returns_close(out, ref)
+    # determinism and seed sensitivity
+    again = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid)
+    assert torch.equal(out, again)
+    other = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid + 1)
+    if not om.deterministic:
+        assert not torch.equal(out, other)
+
+
+def test_device_mode_member_balance_like_the_reference(engine):
+    """tests/core/test_models.py:116-152 on the exported maps: every member gets exactly B / M rows at every step, the
+    assignment changes between steps (TS1) and stays fixed for fixed_model (TS-infinity)."""
+    om = po.make_synthetic_model(17, 6, ensemble_size=5, hid=32, seed=1)
+    spec = to_spec(om, 17, 6)
+    engine.set_model(spec)
+    B, H, M = 2000, 12, 5
+    perms = engine.device_perms(H, B, 3, 1).cpu()
+    member = torch.empty(H, B, dtype=torch.long)
+    for t in range(H):
+        member[t, perms[t]] = torch.arange(B) // (B // M)
+        assert torch.bincount(member[t], minlength=M).tolist() == [B // M] * M
+    assert (member[1:] != member[:-1]).float().mean() > 0.7  # ~ 1 - 1/M of the rows change member between steps
+    om.propagation = "fixed_model"
+    engine.set_model(to_spec(om, 17, 6))
+    assert tuple(engine.device_perms(H, B, 3, 1).shape) == (B,)
+
+
+@pytest.mark.parametrize("prop", ["random_model", "fixed_model", "expectation"])
+@pytest.mark.parametrize("sample", [True, False])
+def test_step_device_mode_matches_oracle(engine, prop, sample):
+    obs, act, B = 17, 6, 240
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=64, seed=5, propagation=prop)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, obs, generator=g) * 0.1
+    a = torch.rand(B, act, generator=g) * 2 - 1
+    nobs, rew, done = engine.step(x.to(DEV), a.to(DEV), mode="device", sample=sample, seed=8, stream_id=3)
+    perm = None
+    if prop != "expectation":
+        perm = engine.device_perms(1, B, 8, 3).cpu()
+        perm = perm if perm.ndim == 1 else perm[0]
+    eps = engine.fast_normals(1, B, 8, 3).cpu()[0]
+    r_nobs, r_rew, r_done = po.step(om, x, a, perm=perm, eps=eps, sample=sample)
+    assert torch.allclose(nobs.cpu(), r_nobs, rtol=1e-5, atol=2e-6)  # T1
+    assert torch.allclose(rew.cpu(), r_rew, rtol=1e-5, atol=2e-6)
+    assert torch.equal(done.cpu(), r_done)
+
+
+def test_eval_fn_device_mode_statistics_match_reference_order_sampling(engine):
+    """mode='device' is the same estimator as the reference (global balanced permutation per step + iid eps): over
+    repeated evaluations its returns have the reference's mean, deterministic under a fixed seed."""
+    obs, act, pop, P, H = 17, 6, 40, 20, 8
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=2)
+    g = torch.Generator().manual_seed(1)
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = np.zeros(obs, np.float32)
+    spec = to_spec(om, obs, act)
+    outs = []
+    for rep in range(2):
+        fn = hipets.make_eval_fn(spec, P, engine=engine, mode="device", seed=4)
+        outs.append(torch.stack([fn(s0, actions.to(DEV)) for _ in range(16)]).cpu())
+    assert torch.equal(outs[0], outs[1])
+    dev_runs = outs[0]
+    torch.manual_seed(0)
+    ref_runs = torch.stack([po.rollout(om, actions, s0, P, global_rng=True, generator=g) for _ in range(16)])
+    se = torch.sqrt(dev_runs.var(0) / 16 + ref_runs.var(0) / 16)
+    z = (dev_runs.mean(0) - ref_runs.mean(0)) / se
+    assert z.abs().max() < 4.5 and abs(z.mean()) < 1.0
+
+
+def test_device_mode_rejects_basic_ensemble_member_maps(engine):
+    om = po.make_synthetic_model(17, 6, ensemble_size=3, hid=32, seed=1, ensemble_kind="basic_ensemble")
+    engine.set_model(to_spec(om, 17, 6))
+    a = torch.zeros(4, 3, 6, device=DEV)
+    with pytest.raises(hipets.HipetsError, match="BasicEnsemble"):
+        engine.rollout(a, np.zeros(17, np.float32), 2, mode="device")

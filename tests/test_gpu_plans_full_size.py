@@ -1,0 +1,284 @@
+"""The BENCHMARKED entry points -- the fused plans hipets_plan_cem / hipets_plan_icem / hipets_plan_mppi -- pinned to the oracle
+at BASELINE.json's full sizes, in both in-kernel randomness modes (DEVICE = reference propagation semantics, FAST).
+
+Every draw a fused plan makes is exportable through the ABI with the plan's own (seed, stream) counters: the population noise
+(the samplers run on a unit problem return their z), DEVICE-mode permutations / FAST-mode member schedules, the rollout eps,
+iCEM's coloured noise and shifted-tail normals.  hipets_set_plan_trace records what the plan did per iteration.  The replay
+feeds those draws to the oracle (bitwise equal to the reference, tests/test_oracle_full_size.py) and checks, per iteration:
+   population  atol 1e-5 | T2 values |err| <= 1e-4 max(1,|v|) | T3 elite sets equal (up to ties within T2 at the boundary) |
+   T4 refit mu / dispersion atol 1e-4 | returned plan == the last refit, bitwise.
+Iterations are teacher-forced (each starts from the engine's recorded state) so that one legitimate tie cannot compound.
+
+Second half: the agents at full size against goldens recorded from the UNMODIFIED reference agent (seed-identical modes)."""
+import numpy as np
+import pytest
+import torch
+
+import hipets
+from conftest import to_spec
+from hipets.planning import _BoundObjective
+from oracle import pets_oracle as po
+from oracle.make_golden import FULL_CASES, full_case_agent_cfg, weights_checksum
+from test_oracle_full_size import load_full
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_case(name):
+    c = FULL_CASES[name]
+    om = po.make_synthetic_model(c["obs"], c["act"], **c["mkw"])
+    s0 = (np.random.default_rng(3).standard_normal(c["obs"]) * 0.1).astype(np.float32)
+    if om.termination == "humanoid":
+        s0[0] = 1.4
+    return c, om, s0
+
+
+def replay_rollout(engine, om, s0, P, H, mode, seed):
+    """objective(population, stream) through the oracle with the engine's exported randomness of (seed, stream)."""
+    def f(population, stream):
+        pop = population.shape[0]
+        B = pop * P
+        eps = engine.fast_normals(H, B, seed, stream).cpu()
+        if mode == "device":
+            return po.rollout(om, population, s0, P, perms=engine.device_perms(H, B, seed, stream).cpu(), eps=eps)
+        nwg, r = engine.fast_geometry(pop, P, H)
+        sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
+        rows = torch.arange(B)
+        wg = ((rows // P) // (16 * r)) * P + rows % P
+        return po.rollout(om, population, s0, P, members=torch.stack([sched[t][wg].long() for t in range(H)]), eps=eps)
+
+    return f
+
+
+def check_values(dev_v, ref_v):
+    tol = 1e-4 * torch.clamp(ref_v.abs(), min=1.0)
+    bad = (dev_v - ref_v).abs() > tol
+    assert not bad.any(), f"T2: max err {(dev_v - ref_v).abs().max():.3e}"
+
+
+def elites_agree(dev_idx, ref_values, K):
+    """T3: same elite set, unless the K-th / (K+1)-th values are within T2 of each other (then either choice is right)."""
+    ref_top = ref_values.topk(K + 1 if ref_values.numel() > K else K)
+    same = set(dev_idx.tolist()) == set(ref_top.indices[:K].tolist())
+    if same or ref_values.numel() <= K:
+        return same
+    gap = float(ref_top.values[K - 1] - ref_top.values[K])
+    assert gap <= 2e-4 * max(1.0, float(ref_top.values[K - 1].abs())), "T3: elite sets differ without a tie at the boundary"
+    return False
+
+
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode):
+    c, om, s0 = make_case("cfg2_cem")
+    obs, act, P, H, pop, iters = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"]
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=5, mode=mode)
+    lower, upper = -torch.ones(H, act), torch.ones(H, act)
+    opt = hipets.CEMOptimizer(iters, 0.1, pop, lower.tolist(), upper.tolist(), 0.1, DEV, return_mean_elites=True, seed=9)
+    K = int(opt.elite_num)
+    x0 = torch.zeros(H, act)
+    for call in range(2):  # the second plan starts from the shifted first plan, like consecutive act() calls
+        tr = engine.set_plan_trace(iters, pop, H, act, K)
+        out = opt.optimize(_BoundObjective(fn, s0), x0=x0)
+        torch.cuda.synchronize()
+        engine.set_plan_trace(0)
+        seed, plan_id = opt.seed ^ fn.seed, opt.calls
+        p = engine.cem_params(pop, H, act, iters, K, 0.1, True, False)
+        one, zero = torch.ones(H, act, device=DEV), torch.zeros(H, act, device=DEV)
+        z = []
+        for i in range(iters):  # the sampler on a unit problem returns its own truncated normals
+            buf = torch.empty(pop, H, act, device=DEV)
+            engine.cem_sample(p, zero, one, -1e3 * one, 1e3 * one, buf, seed=seed, stream_id=plan_id * iters + i)
+            z.append(buf.cpu())
+            assert (buf.abs() <= 2).all()
+        roll = replay_rollout(engine, om, s0, P, H, mode, seed)
+        it = {"i": 0}
+
+        def obj(population):
+            i = it["i"]
+            it["i"] += 1
+            return roll(population, plan_id * iters + i)
+
+        teacher = [(tr["mus"][i].cpu(), tr["dispersions"][i].cpu()) for i in range(iters)]
+        rec = []
+        po.cem_optimize(obj, x0, lower, upper, iters, 0.1, pop, 0.1, return_mean_elites=True, noise=z, record=rec, teacher=teacher)
+        for i in range(iters):
+            assert torch.allclose(tr["populations"][i].cpu(), rec[i]["population"], rtol=0, atol=1e-5), (call, i)
+            check_values(tr["values"][i].cpu(), rec[i]["values"])
+            if elites_agree(tr["elite_idx"][i].cpu(), rec[i]["values"], K):
+                assert int(tr["elite_idx"][i][0]) == int(rec[i]["elite_idx"][0])
+                assert torch.allclose(tr["mus"][i].cpu(), rec[i]["mu"], rtol=0, atol=1e-4), (call, i)  # T4
+                assert torch.allclose(tr["dispersions"][i].cpu(), rec[i]["disp"], rtol=1e-4, atol=1e-5), (call, i)
+        assert torch.equal(out, tr["mus"][iters - 1])
+        x0 = out.cpu().roll(-1, dims=0)
+        x0[-1] = 0.0
+
+
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_fused_mppi_plan_cfg5_replayed_through_oracle(engine, mode):
+    c, om, s0 = make_case("cfg5_mppi")
+    obs, act, P, H, pop, iters = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"]
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=6, mode=mode)
+    lower, upper = -torch.ones(H, act), torch.ones(H, act)
+    opt = hipets.MPPIOptimizer(iters, pop, 0.9, 1.0, 0.9, lower.tolist(), upper.tolist(), DEV, seed=10)
+    st = po.MPPIState(H, act)
+    for call in range(2):  # persistent, shifted mean (Appendix B4-B6)
+        tr = engine.set_plan_trace(iters, pop, H, act, 1)
+        out = opt.optimize(_BoundObjective(fn, s0))
+        torch.cuda.synchronize()
+        engine.set_plan_trace(0)
+        seed, plan_id = opt.seed ^ fn.seed, opt.calls
+        one, zero = torch.ones(H, act, device=DEV), torch.zeros(H, act, device=DEV)
+        z = []
+        for k in range(iters):  # beta = 1, zero mean: the smoothing recurrence returns the raw truncated normals
+            buf = torch.empty(pop, H, act, device=DEV)
+            engine.mppi_sample(pop, H, act, 1.0, zero, torch.zeros(act, device=DEV), -1e3 * one, 1e3 * one, buf, seed=seed,
+                               stream_id=plan_id * iters + k)
+            z.append(buf.cpu())
+        roll = replay_rollout(engine, om, s0, P, H, mode, seed)
+        it = {"i": 0}
+
+        def obj(population):
+            k = it["i"]
+            it["i"] += 1
+            return roll(population, plan_id * iters + k)
+
+        rec = []
+        ref = po.mppi_optimize(obj, st, lower, upper, iters, pop, 0.9, 1.0, 0.9, noise=z, record=rec)
+        for k in range(iters):  # MPPI has no discrete selection: free-running replay, differences stay at rounding level
+            assert torch.allclose(tr["populations"][k].cpu(), rec[k]["population"], rtol=0, atol=2e-5), (call, k)
+            check_values(tr["values"][k].cpu(), rec[k]["values"])
+            assert torch.allclose(tr["mus"][k].cpu(), rec[k]["mean"], rtol=0, atol=1e-4), (call, k)
+        assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-4)
+        assert torch.equal(out, tr["mus"][iters - 1])
+
+
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_fused_icem_plan_cfg4_replayed_through_oracle(engine, mode):
+    """cfg4: 7 members / 5 elites, pop 1000 decaying by 1.3 rounded up to multiples of 7, 35 kept elites, H 40, A 17; the second
+    plan shifts the kept elites (:450-462) and its last iteration evaluates the extra `mu` row (B = (n + 1) P, Appendix B7)."""
+    c, om, s0 = make_case("cfg4_icem")
+    obs, act, P, H, pop, iters, module = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"], c["module"]
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=7, mode=mode)
+    lower, upper = -torch.ones(H, act), torch.ones(H, act)
+    opt = hipets.ICEMOptimizer(iters, 0.1, pop, 1.3, 2.0, lower.tolist(), upper.tolist(), 0.3, 0.1, DEV, return_mean_elites=True,
+                               population_size_module=module, seed=11)
+    K, keep, sizes = po.icem_sizes(iters, 0.1, pop, 1.3, 0.3, module)
+    assert (K, keep, sizes) == (100, 35, [1001, 770, 595, 462, 357])
+    st = po.ICEMState()
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.zeros(H, act)
+    max_rows = sizes[0] + keep
+    one, zero = torch.ones(H, act, device=DEV), torch.zeros(H, act, device=DEV)
+    for call in range(2):
+        keep_perms = [torch.randperm(K, generator=g) for _ in range(iters)]
+        keep_idx = torch.stack([kp[:keep] for kp in keep_perms]).to(torch.int32).to(DEV).contiguous()
+        tr = engine.set_plan_trace(iters, max_rows, H, act, K)
+        had_elite = opt.elite is not None
+        out = opt.optimize(_BoundObjective(fn, s0), x0=x0, keep_idx=keep_idx)
+        torch.cuda.synchronize()
+        engine.set_plan_trace(0)
+        seed, plan_id = opt.seed ^ fn.seed, opt.calls
+        inject, rows = [], []
+        for i in range(iters):
+            sid = (plan_id * iters + i) * 4
+            buf = torch.empty(sizes[i], H, act, device=DEV)
+            engine.icem_sample(sizes[i], H, act, 2.0, zero, one, -1e3 * one, 1e3 * one, buf, seed=seed, stream_id=sid)
+            inj = {"noise": buf.cpu(), "keep_perm": keep_perms[i]}
+            if i == 0 and had_elite:  # tail normals of the shifted elites: the shift kernel on a unit problem returns them
+                sh = torch.empty(keep, H, act, device=DEV)
+                engine.icem_shift(keep, H, act, torch.zeros(keep, H, act, device=DEV), zero, one, sh, seed=seed, stream_id=sid + 1)
+                inj["end_noise"] = sh[:, H - 1, :].cpu()
+            inject.append(inj)
+            extra = 0
+            if had_elite or i > 0:
+                extra = 1 if (i == iters - 1 and i != 0) else keep
+            rows.append(sizes[i] + extra)
+        assert rows[-1] == sizes[-1] + 1  # the +1 mu row
+        roll = replay_rollout(engine, om, s0, P, H, mode, seed)
+        it = {"i": 0}
+
+        def obj(population):
+            i = it["i"]
+            it["i"] += 1
+            assert population.shape[0] == rows[i]
+            return roll(population, (plan_id * iters + i) * 4 + 3)
+
+        teacher = []
+        for i in range(iters):
+            el = tr["populations"][i].cpu()[tr["elite_idx"][i].cpu().long()]
+            teacher.append((tr["mus"][i].cpu(), tr["dispersions"][i].cpu(), el))
+        rec = []
+        po.icem_optimize(obj, st, x0, lower, upper, iters, 0.1, pop, 1.3, 2.0, 0.3, 0.1, return_mean_elites=True,
+                         population_size_module=module, inject=inject, record=rec, teacher=teacher)
+        st.elite = opt.elite.cpu()  # both sides enter the next plan with the engine's elite set
+        for i in range(iters):
+            n = rows[i]
+            assert torch.allclose(tr["populations"][i][:n].cpu(), rec[i]["population"], rtol=0, atol=1e-5), (call, i)
+            check_values(tr["values"][i][:n].cpu(), rec[i]["values"])
+            if elites_agree(tr["elite_idx"][i].cpu(), rec[i]["values"], K):
+                assert torch.allclose(tr["mus"][i].cpu(), rec[i]["mu"], rtol=0, atol=1e-4), (call, i)
+                assert torch.allclose(tr["dispersions"][i].cpu(), rec[i]["var"], rtol=1e-4, atol=1e-5), (call, i)
+        assert torch.equal(out, tr["mus"][iters - 1])
+        x0 = out.cpu().roll(-1, dims=0)
+        x0[-1] = 0.0
+
+
+def test_icem_colored_noise_at_cfg4_size_matches_reference_irfft(engine):
+    """powerlaw_psd_gaussian (util/math.py:318-396) at cfg4's shape (1001 candidates x 17 action dims x H 40): the device's
+    direct inverse real DFT against torch.fft.irfft on the same injected spectrum normals."""
+    n, H, A = 1001, 40, 17
+    g = torch.Generator().manual_seed(3)
+    normals = torch.randn(2, n, A, H // 2 + 1, generator=g)
+    ref = po.powerlaw_psd_gaussian(2.0, size=(n, A, H), normals=(normals[0], normals[1])).transpose(1, 2)
+    one, zero = torch.ones(H, A, device=DEV), torch.zeros(H, A, device=DEV)
+    out = torch.empty(n, H, A, device=DEV)
+    engine.icem_sample(n, H, A, 2.0, zero, one, -1e3 * one, 1e3 * one, out, normals=normals.to(DEV).contiguous())
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=2e-6)
+    assert abs(float(out.var()) - 1.0) < 0.05  # unit variance by construction (:361-363)
+
+
+@pytest.mark.parametrize("mode", ["device", "fast"])
+@pytest.mark.parametrize("kind", ["cem", "mppi"])
+def test_fused_plans_equal_their_per_iteration_paths_with_random_rollouts(engine, mode, kind):
+    """One library call or a host loop over the same kernels with the same counters: bitwise the same plan, also when the
+    rollouts consume randomness (TS1 + Gaussian sampling)."""
+    obs, act, H, P, pop = 17, 6, 10, 5, 120
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=3)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=13, mode=mode)
+    obj = _BoundObjective(fn, (np.random.default_rng(1).standard_normal(obs) * 0.1).astype(np.float32))
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    if kind == "cem":
+        mk = lambda: hipets.CEMOptimizer(4, 0.1, pop, lb, ub, 0.1, DEV, return_mean_elites=True, seed=21)  # noqa: E731
+    else:
+        mk = lambda: hipets.MPPIOptimizer(3, pop, 0.9, 1.0, 0.9, lb, ub, DEV, seed=21)  # noqa: E731
+    a, b = mk(), mk()
+    x0 = torch.zeros(H, act)
+    for _ in range(2):
+        fused = a.optimize(obj, x0=x0)
+        seen = []
+        generic = b.optimize(obj, x0=x0, callback=lambda p_, v_, i_: seen.append(i_))
+        assert torch.equal(fused, generic)
+        assert len(seen) >= 3
+        x0 = fused
+
+
+@pytest.mark.parametrize("name", sorted(FULL_CASES))
+def test_agent_reproduces_the_reference_agent_at_full_size(name):
+    """North star at BASELINE size: TrajectoryOptimizerAgent.act with the torch seeds of the golden (recorded from the unmodified
+    reference agent + ModelEnv on CPU) selects the reference's actions.  sampler='torch' + mode='exact' consume torch's generators
+    in the reference's order; the rollouts run on the GPU kernel."""
+    meta, a = load_full(name)
+    c = FULL_CASES[name]
+    obs, act, P, H = c["obs"], c["act"], c["P"], c["H"]
+    om = po.make_synthetic_model(obs, act, **c["mkw"])
+    assert np.array_equal(weights_checksum(om), meta["weights_checksum"])
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, mode="exact", rng=torch.Generator().manual_seed(meta["generator_seed"]))
+    cfg = full_case_agent_cfg(c, "hipets", DEV, sampler="torch")
+    agent = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H, replan_freq=1)
+    agent.set_trajectory_eval_fn(fn)
+    torch.manual_seed(meta["torch_seed"])
+    for t in range(a["observations"].shape[0]):
+        action = agent.act(a["observations"][t])
+        assert np.allclose(action, a["actions"][t], rtol=0, atol=2e-4), (t, np.abs(action - a["actions"][t]).max())
+        assert np.allclose(agent.optimizer.previous_solution.cpu().numpy(), a["shifted_plans"][t], rtol=0, atol=2e-4)

@@ -330,3 +330,37 @@ def test_planet_spec_extraction_from_live_reference_model(mbrl):
     with torch.no_grad():
         model.reward_model[2].weight.mul_(0.5)
     assert planet_version(model) != v0
+
+
+def test_port_plan_time_matches_the_reference_classes_on_cfg2(mbrl):
+    """bench.py's cpu_baseline times the oracle ("kind": "port") because the reference does not travel to the GPU box.
+    The stand-in is justified: on full cfg2 plans (BASELINE.json configs[1]) the port and the UNMODIFIED reference classes
+    (CEMOptimizer + ModelEnv.evaluate_action_sequences) take the same time within noise, and return bitwise the same plan."""
+    import time
+
+    obs, act, P, H, pop, iters = 17, 6, 20, 30, 500, 5
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0, nontrivial_stats=False)
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    me, _, _ = build_reference_model_env(om, obs, act, generator=torch.Generator().manual_seed(0))
+    ref_opt = mbrl.planning.CEMOptimizer(iters, 0.1, pop, lb, ub, 0.1, "cpu", return_mean_elites=True)
+    gen = torch.Generator().manual_seed(0)
+
+    def ref_plan():
+        return ref_opt.optimize(lambda a: me.evaluate_action_sequences(a, initial_state=s0, num_particles=P), x0=torch.zeros(H, act))
+
+    def port_plan():
+        obj = lambda a: po.rollout(om, a, s0, P, global_rng=True, generator=gen)  # noqa: E731
+        return po.cem_optimize(obj, torch.zeros(H, act), torch.tensor(lb), torch.tensor(ub), iters, 0.1, pop, 0.1, return_mean_elites=True)
+
+    torch.manual_seed(5)
+    r = ref_plan()
+    torch.manual_seed(5)
+    p = port_plan()
+    assert torch.equal(r, p)
+    t_ref, t_port = [], []
+    for _ in range(3):  # interleaved so that machine noise hits both alike
+        t0 = time.perf_counter(); ref_plan(); t_ref.append(time.perf_counter() - t0)  # noqa: E702
+        t0 = time.perf_counter(); port_plan(); t_port.append(time.perf_counter() - t0)  # noqa: E702
+    ratio = min(t_port) / min(t_ref)
+    assert 0.6 < ratio < 1.5, f"port {min(t_port):.3f}s vs reference {min(t_ref):.3f}s per cfg2 plan"
