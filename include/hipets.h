@@ -124,9 +124,12 @@ typedef struct {
     int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
                              /*   workgroup 0, accumulated (profiling aid)                */
     int32_t no_sample;       /* FAST: predictions are the mean (no eps), like ModelEnv.step(sample=False) */
-    int32_t rows_per_member; /* EXACT, BASIC_ENSEMBLE only: perms is [H, M*rows_per_member] ([M*rows_per_member] for  */
-                             /*   fixed_model): slot m*rows_per_member + j = j-th row of member m, -1 = padding        */
-                             /*   (members own unequal row counts under randint, basic_ensemble.py:122-129)            */
+    int32_t rows_per_member; /* EXACT, > 0: explicit per-row member maps.  perms is [H, M*rows_per_member]             */
+                             /*   ([M*rows_per_member] for fixed_model): slot m*rows_per_member + j = j-th row of        */
+                             /*   member m, -1 = padding (members may own unequal row counts).  Required for            */
+                             /*   BASIC_ENSEMBLE (randint maps, basic_ensemble.py:122-129); for GAUSSIAN_MLP it          */
+                             /*   expresses mbrl.util.math.propagate_from_indices (util/math.py:180-196): any            */
+                             /*   row -> member assignment, no batch % members rule                                      */
     int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
                              /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
 } hipets_rollout_opts;
@@ -233,12 +236,13 @@ int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t horizon, int32_t a
  * both its population noise and its rollout (iCEM: 4 * that, + 0..3 for noise / shifted tail / kept-elite draw / rollout). */
 int hipets_set_plan_mode(hipets_engine* e, int32_t mode);
 
-/* Optional per-iteration record of the following fused plans (single-environment plans; NULL pointers are skipped, a NULL
- * trace switches recording off).  All DEVICE, written asynchronously on the plan's stream:
- *   populations [iters, max_rows, H, A]  the candidates iteration i evaluated (rows beyond the iteration's size untouched)
+/* Optional per-iteration record of the following fused plans (NULL pointers are skipped, a NULL trace switches recording
+ * off).  All DEVICE, written asynchronously on the plan's stream; for a batched plan n_env > 1, else n_env = 1:
+ *   populations [iters, max_rows, H, A]  the candidates iteration i evaluated, environment after environment (max_rows
+ *                                        >= n_env * the largest per-environment count; rows beyond an iteration's untouched)
  *   values      [iters, max_rows]        their returns after the NaN filter
- *   mus, dispersions [iters, H, A]       optimizer state after iteration i (MPPI: mus = the refined mean)
- *   elite_idx   [iters, elite_num]       int32, best first (CEM / iCEM)
+ *   mus, dispersions [iters, n_env, H, A]  optimizer state after iteration i (MPPI: mus = the refined mean)
+ *   elite_idx   [iters, n_env, elite_num]  int32, best first, indices into the environment's own candidates (CEM / iCEM)
  * This is what lets a test replay a fused plan through a reference implementation draw by draw.                      */
 typedef struct {
     float* populations;
@@ -271,6 +275,12 @@ int hipets_plan_mppi(hipets_engine* e, int32_t population_size, int32_t horizon,
                      double gamma, double beta, float* mean, const float* lower, const float* upper, const float* s0,
                      int32_t num_particles, uint64_t seed, uint64_t plan_id, void* stream);
 
+/* The same for n_env environments in ONE set of launches (FAST-mode rollouts): mean DEVICE [n_env,H,A] in-out, s0 HOST
+ * [n_env,obs_dim], bounds shared, population_size PER environment.                                               */
+int hipets_plan_mppi_batched(hipets_engine* e, int32_t population_size, int32_t horizon, int32_t act_dim, int32_t num_iterations,
+                             double gamma, double beta, int32_t n_env, float* mean, const float* lower, const float* upper,
+                             const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id, void* stream);
+
 typedef struct {
     int32_t population_size;
     int32_t horizon;
@@ -293,6 +303,13 @@ typedef struct {
 int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
                      float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t num_particles,
                      uint64_t seed, uint64_t plan_id, float* out, void* stream);
+
+/* The same for n_env environments in ONE set of launches (FAST-mode rollouts): x0 / out DEVICE [n_env,H,A], elite DEVICE
+ * [n_env,elite_num,H,A] in-out, keep_idx DEVICE int32 [num_iterations, n_env, keep_elite_size] or NULL, s0 HOST
+ * [n_env,obs_dim]; bounds and the per-iteration population sizes are shared by the environments.                   */
+int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int32_t n_env, const float* x0, const float* lower,
+                             const float* upper, float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0,
+                             int32_t num_particles, uint64_t seed, uint64_t plan_id, float* out, void* stream);
 
 /* ---- multi-GPU: population sharding with ONE all-gather of returns per iteration --------------------- */
 /* The library talks to RCCL itself (librccl is loaded on first use, no link-time dependency): rank 0 makes an id, the
@@ -354,7 +371,9 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
                           int32_t horizon, int32_t num_particles, const hipets_planet_opts* opts, float* returns, void* stream);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
-/* When enabled, every rollout-kernel launch is bracketed by hipEvents on `stream`.              */
+/* on = 1: every rollout-kernel launch carries a start / stop hipEvent pair on its dispatch packet; on = k > 1: every
+ * k-th launch does (a completion signal per packet costs a few microseconds between back-to-back short launches -- the
+ * per-step launches of DEVICE mode -- so bench.py samples them); on = 0: off.                                      */
 int hipets_timing_enable(hipets_engine* e, int32_t on);
 /* Synchronises the recorded events; returns number of launches and their summed duration.       */
 int hipets_timing_read(hipets_engine* e, int64_t* launches, double* total_ms, int32_t reset);

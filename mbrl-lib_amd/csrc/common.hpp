@@ -100,16 +100,25 @@ __host__ __device__ inline uint64_t perm_key(uint64_t seed, uint64_t stream, uin
     return perm_mix64(seed ^ perm_mix64(stream * 0x9E3779B97F4A7C15ull + 0x5045524Dull /* "PERM" */) ^ ((uint64_t)step << 32));
 }
 
-__host__ __device__ inline uint32_t perm_apply(uint32_t x, uint32_t n, uint32_t a, uint32_t b, uint64_t key) {
-    uint32_t k[kPermRounds];
+// the kPermRounds round keys of a permutation (wave-uniform: computed on the host per launch, or once per thread)
+struct PermKeys { uint32_t k[kPermRounds]; };
+__host__ __device__ inline PermKeys perm_round_keys(uint64_t key) {
+    PermKeys pk;
 #pragma unroll
-    for (int r = 0; r < kPermRounds; ++r) k[r] = (uint32_t)(perm_mix64(key + (uint64_t)r) >> 16);
+    for (int r = 0; r < kPermRounds; ++r) pk.k[r] = (uint32_t)(perm_mix64(key + (uint64_t)r) >> 16);
+    return pk;
+}
+
+// uniform map of a 32-bit hash onto [0, m): floor(h * m / 2^32) (one multiply-high instead of a division)
+__host__ __device__ inline uint32_t perm_scale(uint32_t h, uint32_t m) { return (uint32_t)(((uint64_t)h * m) >> 32); }
+
+__host__ __device__ inline uint32_t perm_apply(uint32_t x, uint32_t n, uint32_t a, uint32_t b, const PermKeys& pk) {
     do {
-        uint32_t L = x / b, R = x % b;  // x = L * b + R, L in [0, a), R in [0, b)
+        uint32_t L = x / b, R = x - L * b;  // x = L * b + R, L in [0, a), R in [0, b)
 #pragma unroll
         for (int r = 0; r < kPermRounds; ++r) {
-            if (r & 1) { R += perm_hash(L, k[r]) % b; if (R >= b) R -= b; }  // R, hash % b < b < 2^16: no overflow
-            else { L += perm_hash(R, k[r]) % a; if (L >= a) L -= a; }
+            if (r & 1) { R += perm_scale(perm_hash(L, pk.k[r]), b); if (R >= b) R -= b; }  // R, increment < b < 2^16: no overflow
+            else { L += perm_scale(perm_hash(R, pk.k[r]), a); if (L >= a) L -= a; }
         }
         x = L * b + R;
     } while (x >= n);

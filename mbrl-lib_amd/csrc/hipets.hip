@@ -90,8 +90,10 @@ struct hipets_engine {
     int plan_mode = HIPETS_MODE_FAST;
     bool has_trace = false;
     hipets_plan_trace trace{};
-    // timing
+    // timing: every timing_stride-th rollout-kernel launch carries a start / stop event pair on its dispatch packet
     bool timing = false;
+    int timing_stride = 1;
+    unsigned long long launch_counter = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
 };
@@ -100,7 +102,8 @@ namespace {
 
 int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
     hipEvent_t a = nullptr, b = nullptr;
-    if (e->timing) {
+    const bool timed = e->timing && (e->launch_counter++ % (unsigned long long)e->timing_stride) == 0;
+    if (timed) {
         if (!e->event_pool.empty()) {
             a = e->event_pool.back().first;
             b = e->event_pool.back().second;
@@ -118,7 +121,7 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
         case 4: err = launch_rollout_r4(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
         default: return fail("unsupported rows_per_group %d (1..%d)", R, kMaxR);
     }
-    if (e->timing) e->events.emplace_back(a, b);  // recorded (or leaked to the pool) either way
+    if (timed) e->events.emplace_back(a, b);  // recorded (or leaked to the pool) either way
     if (err != hipSuccess) return fail("rollout kernel launch failed: %s", hipGetErrorString(err));
     return 0;
 }
@@ -240,15 +243,16 @@ __global__ void unpad_shards_kernel(const float* gathered, float* values, int po
 // hipets_set_plan_trace: record iteration i of a fused plan (population as evaluated, values after the NaN filter, refitted
 // mean / dispersion) into the caller's buffers.  A no-op unless a trace is set.
 int trace_iter(hipets_engine* e, int i, int rows, size_t nd, const float* population, const float* values, const float* mu,
-               const float* disp, hipStream_t st) {
+               const float* disp, hipStream_t st, int n_env = 1) {
     if (!e->has_trace) return 0;
     const hipets_plan_trace& t = e->trace;
     if (rows > t.max_rows) return fail("plan trace: iteration %d evaluates %d candidates, trace buffers hold %d", i, rows, t.max_rows);
+    const size_t ne = (size_t)n_env;
     if (t.populations && population)
         HCHECK(hipMemcpyAsync(t.populations + (size_t)i * t.max_rows * nd, population, (size_t)rows * nd * 4, hipMemcpyDeviceToDevice, st));
     if (t.values && values) HCHECK(hipMemcpyAsync(t.values + (size_t)i * t.max_rows, values, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
-    if (t.mus && mu) HCHECK(hipMemcpyAsync(t.mus + (size_t)i * nd, mu, nd * 4, hipMemcpyDeviceToDevice, st));
-    if (t.dispersions && disp) HCHECK(hipMemcpyAsync(t.dispersions + (size_t)i * nd, disp, nd * 4, hipMemcpyDeviceToDevice, st));
+    if (t.mus && mu) HCHECK(hipMemcpyAsync(t.mus + (size_t)i * ne * nd, mu, ne * nd * 4, hipMemcpyDeviceToDevice, st));
+    if (t.dispersions && disp) HCHECK(hipMemcpyAsync(t.dispersions + (size_t)i * ne * nd, disp, ne * nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -514,17 +518,21 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         const bool device = o->mode == HIPETS_MODE_DEVICE;
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
-        if (!md.iid_members && B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
+        // explicit per-row member maps (padded member slots, opts.rows_per_member): what BasicEnsemble draws with randint
+        // (basic_ensemble.py:122-129) and what mbrl.util.math.propagate_from_indices expresses (util/math.py:180-196);
+        // accepted for GaussianMLP models too (any batch size, members may own unequal row counts)
+        const bool slots = !device && !expectation && o->rows_per_member > 0;
+        if (!md.iid_members && !slots && B % md.M != 0)  // the reference's ValueError (gaussian_mlp.py:195-200), raised for every propagation method
             return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
                         "Current batch size is %lld for %d models.", B, md.M);
         if (!expectation) {
             if (device && md.iid_members)
                 return fail("DEVICE mode has no BasicEnsemble (iid member map) variant: use FAST, or EXACT with injected maps");
             if (!device && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
-            if (md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
-                return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
+            if ((md.iid_members && !device && !slots) || (slots && o->rows_per_member > B))
+                return fail("EXACT mode with per-row member maps needs opts.rows_per_member in [1, B] (padded member slots)");
         }
-        const int rpd = expectation ? (int)B : (md.iid_members ? o->rows_per_member : (int)(B / domains));
+        const int rpd = expectation ? (int)B : (slots ? o->rows_per_member : (int)(B / domains));
         const long long tiles = (rpd + kTile - 1) / kTile;
         const int R = choose_R(e, tiles, domains, o->rows_per_group, H);
         const size_t lds = lds_for(e, R, H);
@@ -546,7 +554,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             if (!expectation) {
                 ra.perm_n = (unsigned)B;
                 perm_radices((uint32_t)B, &ra.perm_a, &ra.perm_b);
-                ra.perm_fixed = md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0;
+                ra.perm_keys = perm_round_keys(perm_key(o->seed, o->stream_id, 0xFFFFFFFFu));  // fixed_model; random_model: per step below
             }
         } else {
             ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
@@ -561,6 +569,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             for (int t = 0; t < H; ++t) {
                 ra.t_begin = t;
                 ra.t_end = t + 1;
+                if (ra.perm_n) ra.perm_keys = perm_round_keys(perm_key(o->seed, o->stream_id, (uint32_t)t));  // this step's permutation
                 if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
             }
         } else {
@@ -617,7 +626,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     HCHECK(hipSetDevice(e->device));
     const ModelDev& md = e->md;
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
-    if (!md.iid_members && B % md.M != 0)  // gaussian_mlp.py:195-200
+    if (!md.iid_members && B % md.M != 0 && !(o->mode == HIPETS_MODE_EXACT && o->rows_per_member > 0))  // gaussian_mlp.py:195-200
         return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
                     "Current batch size is %d for %d models.", B, md.M);
     // the kernel updates state / totals / terminated in place: run it on the caller's output buffers
@@ -643,12 +652,13 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         const bool device = o->mode == HIPETS_MODE_DEVICE;
         const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
         const int domains = expectation ? 1 : md.M;
+        const bool slots = !device && !expectation && o->rows_per_member > 0;  // explicit per-row member maps, see hipets_rollout
         if (!expectation && device && md.iid_members)
             return fail("DEVICE mode has no BasicEnsemble (iid member map) variant: use FAST, or EXACT with injected maps");
         if (!expectation && !device && !o->perms) return fail("EXACT mode with random_model/fixed_model propagation needs opts.perms");
-        if (!expectation && md.iid_members && (o->rows_per_member < 1 || o->rows_per_member > B))
-            return fail("BasicEnsemble EXACT mode needs opts.rows_per_member in [1, B] (padded member slots)");
-        const int rpd = expectation ? B : (md.iid_members ? o->rows_per_member : B / domains);
+        if (!expectation && ((md.iid_members && !device && !slots) || (slots && o->rows_per_member > B)))
+            return fail("EXACT mode with per-row member maps needs opts.rows_per_member in [1, B] (padded member slots)");
+        const int rpd = expectation ? B : (slots ? o->rows_per_member : B / domains);
         const long long tiles = (rpd + kTile - 1) / kTile;
         const int R = choose_R(e, tiles, domains, o->rows_per_group, 1);
         const size_t lds = lds_for(e, R, 1);
@@ -660,7 +670,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
             if (!expectation) {
                 ra.perm_n = (unsigned)B;
                 perm_radices((uint32_t)B, &ra.perm_a, &ra.perm_b);
-                ra.perm_fixed = md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0;
+                ra.perm_keys = perm_round_keys(perm_key(o->seed, o->stream_id, md.propagation == HIPETS_PROP_FIXED_MODEL ? 0xFFFFFFFFu : 0u));
             }
         } else {
             ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
@@ -789,7 +799,7 @@ int hipets_gather_rows(hipets_engine* e, int32_t rows, int32_t dim, const float*
     HCHECK(hipSetDevice(e->device));
     const long long n = (long long)rows * dim;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows,
-                       dim, src, index, dst);
+                       dim, src, index, dst, 0ll, 0ll);
     HCHECK(hipGetLastError());
     return 0;
 }
@@ -801,7 +811,7 @@ int hipets_mppi_sample(hipets_engine* e, int32_t pop, int32_t H, int32_t A, doub
     if (pop < 1 || H < 1 || A < 1) return fail("bad pop/horizon/act_dim");
     HCHECK(hipSetDevice(e->device));
     const int n = pop * A;
-    hipLaunchKernelGGL(mppi_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pop, H, A,
+    hipLaunchKernelGGL(mppi_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), 1, pop, H, A,
                        (float)beta, mean, past_action, lower, upper, z, (unsigned long long)seed, (unsigned long long)stream_id,
                        population);
     HCHECK(hipGetLastError());
@@ -827,7 +837,7 @@ int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t H, int32_t A, double
     if (H < 2 || H > kMaxHorizon) return fail("iCEM horizon %d outside [2, %d]", H, kMaxHorizon);
     HCHECK(hipSetDevice(e->device));
     const int total = n * A;
-    hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), n, H, A,
+    hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), 1, n, n, H, A,
                        (float)exponent, mu, var, lower, upper, normals, (unsigned long long)seed, (unsigned long long)stream_id,
                        population);
     HCHECK(hipGetLastError());
@@ -840,7 +850,7 @@ int hipets_icem_shift(hipets_engine* e, int32_t keep, int32_t H, int32_t A, cons
     if (keep < 1 || H < 1 || A < 1) return fail("bad keep/horizon/act_dim");
     HCHECK(hipSetDevice(e->device));
     const int n = keep * H * A;
-    hipLaunchKernelGGL(icem_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keep, H, A, kept,
+    hipLaunchKernelGGL(icem_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), 1, keep, keep, H, A, kept,
                        mu, var, end_noise, (unsigned long long)seed, (unsigned long long)stream_id, out);
     HCHECK(hipGetLastError());
     return 0;
@@ -893,12 +903,12 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
         if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream,
                          sched ? sched + (size_t)i * sched_stride : nullptr))
             return 1;
-        int* eidx = (e->has_trace && n_env == 1 && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
+        int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * n_env * c.K : nullptr;
         hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
-        if (n_env == 1 && trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st))
+        if (trace_iter(e, i, (int)npop, (size_t)c.D, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st, n_env))
             return 1;
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
@@ -908,38 +918,51 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
 int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta,
                      float* mean, const float* lower, const float* upper, const float* s0, int32_t P, uint64_t seed,
                      uint64_t plan_id, void* stream) {
+    return hipets_plan_mppi_batched(e, pop, H, A, num_iterations, gamma, beta, 1, mean, lower, upper, s0, P, seed, plan_id, stream);
+}
+
+int hipets_plan_mppi_batched(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta,
+                             int32_t n_env, float* mean, const float* lower, const float* upper, const float* s0, int32_t P,
+                             uint64_t seed, uint64_t plan_id, void* stream) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!mean || !lower || !upper || !s0) return fail("null argument");
     if (pop < 1 || pop > 12000) return fail("population_size %d outside [1, 12000]", pop);
     if (H < 1 || num_iterations < 0) return fail("bad horizon/num_iterations");
     if (A != e->md.act_dim) return fail("act_dim %d != model act_dim %d", A, e->md.act_dim);
+    if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
+    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    const size_t nd = (size_t)H * A;
-    if (e->mu.ensure(nd * 4) || e->past_action.ensure((size_t)A * 4) || e->population.ensure((size_t)pop * nd * 4) ||
-        e->values.ensure((size_t)pop * 4))
+    const size_t nd = (size_t)H * A, npop = (size_t)n_env * pop;
+    if (e->mu.ensure(n_env * nd * 4) || e->past_action.ensure((size_t)n_env * A * 4) || e->population.ensure(npop * nd * 4) ||
+        e->values.ensure(npop * 4))
         return 1;
-    HCHECK(hipMemcpyAsync(e->mu.p, mean, nd * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, H, A, e->mu.as<float>(), mean,
+    HCHECK(hipMemcpyAsync(e->mu.p, mean, n_env * nd * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((n_env * nd + 255) / 256)), dim3(256), 0, st, n_env, H, A, e->mu.as<float>(), mean,
                        e->past_action.as<float>());
     HCHECK(hipGetLastError());
     hipets_rollout_opts ro{};
     ro.mode = e->plan_mode;
     ro.seed = seed;
+    ro.n_env = n_env;
     const int* sched = nullptr;
     size_t sched_stride = 0;
-    if (plan_prologue(e, s0, 1, pop, P, H, num_iterations, seed, plan_id * (uint64_t)num_iterations, st, &sched, &sched_stride)) return 1;
+    if (plan_prologue(e, s0, n_env, (int)npop, P, H, num_iterations, seed, plan_id * (uint64_t)num_iterations, st, &sched, &sched_stride)) return 1;
     for (int k = 0; k < num_iterations; ++k) {
         const uint64_t sid = plan_id * (uint64_t)num_iterations + (uint64_t)k;
-        if (hipets_mppi_sample(e, pop, H, A, beta, mean, e->past_action.as<float>(), lower, upper, nullptr, seed, sid,
-                               e->population.as<float>(), stream))
-            return 1;
+        const long long n = (long long)npop * A;
+        hipLaunchKernelGGL(mppi_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_env, pop, H, A, (float)beta, mean,
+                           e->past_action.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
+                           e->population.as<float>());
+        HCHECK(hipGetLastError());
         ro.stream_id = sid;
-        if (rollout_impl(e, e->population.as<float>(), nullptr, pop, H, P, &ro, e->values.as<float>(), stream,
+        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, H, P, &ro, e->values.as<float>(), stream,
                          sched ? sched + (size_t)k * sched_stride : nullptr))
             return 1;
-        if (hipets_mppi_update(e, pop, H, A, gamma, e->values.as<float>(), e->population.as<float>(), mean, stream)) return 1;
-        if (trace_iter(e, k, pop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st)) return 1;
+        hipLaunchKernelGGL(mppi_update_kernel, dim3(n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
+                           e->values.as<float>(), e->population.as<float>(), mean);
+        HCHECK(hipGetLastError());
+        if (trace_iter(e, k, (int)npop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st, n_env)) return 1;
     }
     return 0;
 }
@@ -947,6 +970,12 @@ int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_
 int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
                      float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed,
                      uint64_t plan_id, float* out, void* stream) {
+    return hipets_plan_icem_batched(e, p, 1, x0, lower, upper, elite, has_elite, keep_idx, s0, P, seed, plan_id, out, stream);
+}
+
+int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int32_t n_env, const float* x0, const float* lower,
+                             const float* upper, float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P,
+                             uint64_t seed, uint64_t plan_id, float* out, void* stream) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!p || !x0 || !lower || !upper || !elite || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
@@ -954,6 +983,8 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
     const int K = p->elite_num, keep = p->keep_elite_size, iters = p->num_iterations, H = p->horizon, A = p->act_dim;
     if (K < 1 || keep < 0 || keep > K) return fail("elite_num %d / keep_elite_size %d invalid", K, keep);
     if (p->population_size < 1 || iters < 0 || !(p->population_decay_factor > 0.0)) return fail("bad iCEM parameters");
+    if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
+    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     // population sizes (:419-431) are known up front: size the workspace for the largest
@@ -967,11 +998,10 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
         if (n + keep > kMaxPop) return fail("iCEM iteration %d evaluates %d candidates (max %d)", i, n + keep, kMaxPop);
         max_rows = std::max(max_rows, n + keep);
     }
-    const size_t nd = (size_t)H * A;
-    if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
-        e->population.ensure((size_t)max_rows * nd * 4) || e->values.ensure((size_t)max_rows * 4) ||
-        e->kept.ensure((size_t)std::max(keep, 1) * nd * 4) || e->elite_idx.ensure((size_t)K * 4) ||
-        e->keep_idx.ensure((size_t)std::max(keep, 1) * 4))
+    const size_t nd = (size_t)H * A, ne = (size_t)n_env;
+    if (e->mu.ensure(ne * nd * 4) || e->disp.ensure(ne * nd * 4) || e->best_solution.ensure(ne * nd * 4) || e->best_value.ensure(ne * 4 + 16) ||
+        e->population.ensure(ne * max_rows * nd * 4) || e->values.ensure(ne * max_rows * 4) ||
+        e->kept.ensure(ne * std::max(keep, 1) * nd * 4) || e->elite_idx.ensure(ne * K * 4) || e->keep_idx.ensure(ne * std::max(keep, 1) * 4))
         return 1;
     hipets_cem_params cp{};
     cp.population_size = std::max(K, 1);
@@ -983,63 +1013,77 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
     cp.return_mean_elites = p->return_mean_elites;
     cp.clipped_normal = 0;  // initial variance ((ub - lb)^2) / 16 (:373) and variance (not std) refit
     cp.unbiased_var = 0;    // :479
-    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, make_cem(&cp), x0, lower, upper,
+    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((ne * nd + 255) / 256)), dim3(256), 0, st, make_cem(&cp, n_env), x0, lower, upper,
                        e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>());
     HCHECK(hipGetLastError());
-    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, ne * nd * 4, st));
     hipets_rollout_opts ro{};
     ro.mode = e->plan_mode;
     ro.seed = seed;
-    if (e->s0.ensure((size_t)e->md.obs_dim * 4)) return 1;  // the observation is the same for every iteration: stage it once
-    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)e->md.obs_dim * 4, hipMemcpyHostToDevice, st));
-    float* popbuf = e->population.as<float>();
+    ro.n_env = n_env;
+    if (e->s0.ensure(ne * e->md.obs_dim * 4)) return 1;  // the observations are the same for every iteration: stage them once
+    HCHECK(hipMemcpyAsync(e->s0.p, s0, ne * e->md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    float* popbuf = e->population.as<float>();  // [n_env][rows][H][A], rows = this iteration's candidates per environment
     for (int i = 0; i < iters; ++i) {
         const int n = sizes[i];
         const uint64_t sid = (plan_id * (uint64_t)iters + (uint64_t)i) * 4;
         int extra = 0;
         if (has_elite) extra = (i == iters - 1 && i != 0) ? 1 : keep;
-        if (hipets_icem_sample(e, n, H, A, p->colored_noise_exponent, e->mu.as<float>(), e->disp.as<float>(), lower, upper, nullptr,
-                               seed, sid, popbuf, stream))
-            return 1;
+        const int rows = n + extra;
+        const int total = n_env * n * A;
+        hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, st, n_env, rows, n, H, A, (float)p->colored_noise_exponent,
+                           e->mu.as<float>(), e->disp.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed,
+                           (unsigned long long)sid, popbuf);
+        HCHECK(hipGetLastError());
         if (extra) {
-            float* tail = popbuf + (size_t)n * nd;
+            float* tail = popbuf + (size_t)n * nd;  // environment 0's extra rows; the others follow rows * nd floats apart
             if (i == iters - 1 && i != 0) {  // :463-464
-                HCHECK(hipMemcpyAsync(tail, e->mu.p, nd * 4, hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(icem_append_mu_kernel, dim3((unsigned)((ne * nd + 255) / 256)), dim3(256), 0, st, n_env, rows, n, (int)nd,
+                                   e->mu.as<float>(), popbuf);
+                HCHECK(hipGetLastError());
             } else {
-                const int32_t* kidx = keep_idx ? keep_idx + (size_t)i * keep : e->keep_idx.as<int32_t>();
+                const int32_t* kidx = keep_idx ? keep_idx + (size_t)i * n_env * keep : e->keep_idx.as<int32_t>();
                 if (!keep_idx) {
-                    hipLaunchKernelGGL(icem_keep_select_kernel, dim3(1), dim3(256), (size_t)K * 8, st, K, keep, (unsigned long long)seed,
+                    hipLaunchKernelGGL(icem_keep_select_kernel, dim3(n_env), dim3(256), (size_t)K * 8, st, K, keep, (unsigned long long)seed,
                                        (unsigned long long)(sid + 2), e->keep_idx.as<int32_t>());
                     HCHECK(hipGetLastError());
                 }
-                if (i == 0) {  // :450-462
-                    if (hipets_gather_rows(e, keep, (int32_t)nd, elite, kidx, e->kept.as<float>(), stream)) return 1;
-                    if (hipets_icem_shift(e, keep, H, A, e->kept.as<float>(), e->mu.as<float>(), e->disp.as<float>(), nullptr, seed,
-                                          sid + 1, tail, stream))
-                        return 1;
+                const long long ng = (long long)keep * nd;
+                if (i == 0) {  // :450-462: kept elites shifted one step with a fresh tail action
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
+                                       e->kept.as<float>(), (long long)K * nd, (long long)keep * nd);
+                    HCHECK(hipGetLastError());
+                    hipLaunchKernelGGL(icem_shift_kernel, dim3((unsigned)((ne * ng + 255) / 256)), dim3(256), 0, st, n_env, rows, keep, H, A,
+                                       e->kept.as<float>(), e->mu.as<float>(), e->disp.as<float>(), (const float*)nullptr,
+                                       (unsigned long long)seed, (unsigned long long)(sid + 1), tail);
+                    HCHECK(hipGetLastError());
                 } else {  // :465-466
-                    if (hipets_gather_rows(e, keep, (int32_t)nd, elite, kidx, tail, stream)) return 1;
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
+                                       tail, (long long)K * nd, (long long)rows * nd);
+                    HCHECK(hipGetLastError());
                 }
             }
         }
-        const int rows = n + extra;
         ro.stream_id = sid + 3;
-        if (rollout_impl(e, popbuf, nullptr, rows, H, P, &ro, e->values.as<float>(), stream, nullptr)) return 1;  // s0 staged above
+        if (rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream, nullptr)) return 1;  // s0 staged above
         cp.population_size = rows;
         if (check_cem(&cp)) return 1;
         int n2 = 1;
         while (n2 < rows) n2 <<= 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp), e->values.as<float>(), popbuf,
-                           e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(), e->best_solution.as<float>(),
-                           e->elite_idx.as<int>());
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
+                           e->values.as<float>(), popbuf, e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                           e->best_solution.as<float>(), e->elite_idx.as<int>());
         HCHECK(hipGetLastError());
-        if (hipets_gather_rows(e, K, (int32_t)nd, popbuf, e->elite_idx.as<int32_t>(), elite, stream)) return 1;  // :476
+        const long long nk = (long long)K * nd;  // self.elite = population[elite_idx] (:476), per environment
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nk + 255) / 256), n_env), dim3(256), 0, st, K, (int)nd, popbuf, e->elite_idx.as<int32_t>(),
+                           elite, (long long)rows * nd, (long long)K * nd);
+        HCHECK(hipGetLastError());
         has_elite = 1;
-        if (trace_iter(e, i, rows, nd, popbuf, e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st)) return 1;
+        if (trace_iter(e, i, n_env * rows, nd, popbuf, e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st, n_env)) return 1;
         if (e->has_trace && e->trace.elite_idx)
-            HCHECK(hipMemcpyAsync(e->trace.elite_idx + (size_t)i * K, e->elite_idx.p, (size_t)K * 4, hipMemcpyDeviceToDevice, st));
+            HCHECK(hipMemcpyAsync(e->trace.elite_idx + (size_t)i * n_env * K, e->elite_idx.p, ne * K * 4, hipMemcpyDeviceToDevice, st));
     }
-    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, ne * nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -1252,6 +1296,8 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
 int hipets_timing_enable(hipets_engine* e, int32_t on) {
     if (!e) return fail("null engine");
     e->timing = on != 0;
+    e->timing_stride = on > 1 ? on : 1;
+    e->launch_counter = 0;
     return 0;
 }
 

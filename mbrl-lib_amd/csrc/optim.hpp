@@ -16,13 +16,16 @@ namespace hipets {
 // trajectory_opt.py:262-295.  One thread per (candidate, action dim) walks the horizon: the beta-smoothing
 // recurrence (:279-287) runs on UNCLIPPED values, clipping (:290-295) is applied to what is stored.
 // Appendix B5: sigma never reaches the population (the scaled noise of :276 is fully overwritten).
-__global__ void mppi_sample_kernel(int pop, int H, int A, float beta, const float* __restrict__ mean,
+__global__ void mppi_sample_kernel(int n_env, int pop, int H, int A, float beta, const float* __restrict__ mean,
                                    const float* __restrict__ past_action, const float* __restrict__ lower,
                                    const float* __restrict__ upper, const float* __restrict__ z_in, unsigned long long seed,
                                    unsigned long long stream, float* __restrict__ population) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pop * A) return;
-    const int c = i / A, a = i % A;
+    if (i >= n_env * pop * A) return;
+    const int c = i / A, a = i % A;  // c: candidate over all environments (environment c / pop owns mean / past_action)
+    const int env = c / pop;
+    mean += (size_t)env * H * A;
+    past_action += (size_t)env * A;
     const float omb = 1.0f - beta;
     float prev = past_action[a];
     for (int h = 0; h < H; ++h) {
@@ -45,6 +48,12 @@ __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int 
     float* w = reinterpret_cast<float*>(smem);                // [pop]
     float* red = w + pop;                                     // [kMppiThreads]
     const int tid = threadIdx.x;
+    {  // one workgroup per environment
+        const int env = blockIdx.x;
+        values += (size_t)env * pop;
+        population += (size_t)env * pop * D;
+        mean += (size_t)env * D;
+    }
     float m = -INFINITY;
     for (int i = tid; i < pop; i += kMppiThreads) {
         float v = values[i];
@@ -86,8 +95,8 @@ __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int 
 // Nyquist imaginary parts zero), inverts them with a direct real DFT (H <= 64 here: O(H^2) per series is a few
 // thousand FMAs) and normalises by the theoretical std so the series has unit variance.
 constexpr int kMaxHorizon = 128;
-__global__ void icem_sample_kernel(int n, int H, int A, float exponent, const float* __restrict__ mu, const float* __restrict__ var,
-                                   const float* __restrict__ lower, const float* __restrict__ upper,
+__global__ void icem_sample_kernel(int n_env, int row_stride, int n, int H, int A, float exponent, const float* __restrict__ mu,
+                                   const float* __restrict__ var, const float* __restrict__ lower, const float* __restrict__ upper,
                                    const float* __restrict__ normals /* [2, n, A, H/2+1] or null */, unsigned long long seed,
                                    unsigned long long stream, float* __restrict__ population) {
     __shared__ float cs[kMaxHorizon], sn[kMaxHorizon], scale[kMaxHorizon / 2 + 1];
@@ -116,9 +125,14 @@ __global__ void icem_sample_kernel(int n, int H, int A, float exponent, const fl
         sigma_s = 2.0f * sqrtf(acc) / (float)H;
     }
     __syncthreads();
+    // n_env environments sample n rows each into population [n_env][row_stride][H][A] from their own mu / var [n_env][H][A]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * A) return;
-    const int c = i / A, a = i % A;
+    if (i >= n_env * n * A) return;
+    const int env = i / (n * A);
+    const int c = (i % (n * A)) / A, a = i % A;
+    mu += (size_t)env * H * A;
+    var += (size_t)env * H * A;
+    population += (size_t)env * row_stride * H * A;
     float re[kMaxHorizon / 2 + 1], im[kMaxHorizon / 2 + 1];
     for (int f = 0; f < NF; ++f) {
         float nr, ni;
@@ -156,31 +170,37 @@ __global__ void icem_sample_kernel(int n, int H, int A, float exponent, const fl
 }
 
 // trajectory_opt.py:450-462: kept elites shifted one step, tail action ~ N(mu[-1], sqrt(var[-1]))
-__global__ void icem_shift_kernel(int keep, int H, int A, const float* __restrict__ kept, const float* __restrict__ mu,
-                                  const float* __restrict__ var, const float* __restrict__ end_noise /* [keep, A] or null */,
-                                  unsigned long long seed, unsigned long long stream, float* __restrict__ out) {
+__global__ void icem_shift_kernel(int n_env, int row_stride, int keep, int H, int A, const float* __restrict__ kept,
+                                  const float* __restrict__ mu, const float* __restrict__ var,
+                                  const float* __restrict__ end_noise /* [keep, A] or null */, unsigned long long seed,
+                                  unsigned long long stream, float* __restrict__ out) {
+    // kept [n_env][keep][H][A]; out: `keep` rows per environment, environments row_stride rows apart
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= keep * H * A) return;
-    const int a = i % A, h = (i / A) % H, j = i / (A * H);
+    if (i >= n_env * keep * H * A) return;
+    const int a = i % A, h = (i / A) % H, jg = i / (A * H);  // jg: kept row over all environments
+    const int env = jg / keep, j = jg % keep;
+    const size_t o = ((size_t)env * row_stride + j) * H * A + (size_t)h * A + a;
     if (h < H - 1) {
-        out[i] = kept[((size_t)j * H + h + 1) * A + a];
+        out[o] = kept[((size_t)jg * H + h + 1) * A + a];
     } else {
         const int d = (H - 1) * A + a;
-        const float z = end_noise ? end_noise[j * A + a]
-                                  : philox_normal((uint32_t)(j * A + a), 0x5E1Fu, seed, stream ^ 0x9E3779B97F4A7C15ull);
-        out[i] = mu[d] + sqrtf(var[d]) * z;
+        const float z = end_noise ? end_noise[jg * A + a]
+                                  : philox_normal((uint32_t)(jg * A + a), 0x5E1Fu, seed, stream ^ 0x9E3779B97F4A7C15ull);
+        out[o] = mu[(size_t)env * H * A + d] + sqrtf(var[(size_t)env * H * A + d]) * z;
     }
 }
 
 // MPPIOptimizer.optimize prologue (trajectory_opt.py:257-258): mean[:-1] = mean[1:] (the last row stays) and
 // past_action = the ALREADY shifted mean[0] (Appendix B5).  `src` is a private copy of the caller's mean.
-__global__ void mppi_shift_kernel(int H, int A, const float* __restrict__ src, float* __restrict__ mean, float* __restrict__ past_action) {
+__global__ void mppi_shift_kernel(int n_env, int H, int A, const float* __restrict__ src, float* __restrict__ mean,
+                                  float* __restrict__ past_action) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * A) return;
-    const int t = i / A, a = i % A;
-    const float v = src[(t + 1 < H ? t + 1 : t) * A + a];
+    if (i >= n_env * H * A) return;
+    const int env = i / (H * A), r = i % (H * A);
+    const int t = r / A, a = r % A;
+    const float v = src[(size_t)env * H * A + (t + 1 < H ? t + 1 : t) * A + a];
     mean[i] = v;
-    if (t == 0) past_action[a] = v;
+    if (t == 0) past_action[env * A + a] = v;
 }
 
 // `keep` distinct indices drawn uniformly from [0, K) in random order: the law of torch.randperm(K)[:keep]
@@ -190,8 +210,9 @@ __global__ __launch_bounds__(256) void icem_keep_select_kernel(int K, int keep, 
                                                               int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    out += (size_t)blockIdx.x * keep;  // one workgroup (and one independent draw) per environment
     for (int j = threadIdx.x; j < K; j += blockDim.x) {
-        const Philox4 r = philox4x32_10((uint32_t)j, 0x4B454550u, 0u, (uint32_t)stream, (uint32_t)seed,
+        const Philox4 r = philox4x32_10((uint32_t)j, 0x4B454550u, (uint32_t)blockIdx.x, (uint32_t)stream, (uint32_t)seed,
                                         (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32) ^ 0x5EED5EEDu);
         keys[j] = ((unsigned long long)r.x << 32) | r.y;
     }
@@ -205,10 +226,21 @@ __global__ __launch_bounds__(256) void icem_keep_select_kernel(int K, int keep, 
 }
 
 // rows of `src` selected by `index` (int64, like torch.index_select) -> dst; used for population[elite_idx]
-__global__ void gather_rows_kernel(int rows, int D, const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst) {
+__global__ void gather_rows_kernel(int rows, int D, const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst,
+                                   long long src_env_stride, long long dst_env_stride) {
+    // blockIdx.y = environment: src / dst advance by their environment strides (floats), index by `rows`
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * D) return;
-    dst[i] = src[(size_t)index[i / D] * D + (i % D)];
+    const int env = blockIdx.y;
+    dst[(size_t)env * dst_env_stride + i] = src[(size_t)env * src_env_stride + (size_t)index[(size_t)env * rows + i / D] * D + (i % D)];
+}
+
+// trajectory_opt.py:463-464 for every environment: the extra candidate of the last iteration is the current mean
+__global__ void icem_append_mu_kernel(int n_env, int row_stride, int row, int D, const float* __restrict__ mu, float* __restrict__ population) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_env * D) return;
+    const int env = i / D, d = i % D;
+    population[((size_t)env * row_stride + row) * D + d] = mu[i];
 }
 
 }  // namespace hipets

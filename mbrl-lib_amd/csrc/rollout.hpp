@@ -74,7 +74,7 @@ struct RolloutArgs {
     const long long* perm; // EXACT: [H,B] / [B] / null
     long long perm_step;   // stride between steps (0 for fixed_model)
     unsigned perm_n, perm_a, perm_b;  // DEVICE mode: row of slot j = perm_apply(j) over [0, perm_n), radices a x b (perm_n = 0: none)
-    int perm_fixed;        // DEVICE mode: one permutation for the whole horizon (fixed_model) instead of one per step
+    PermKeys perm_keys;    // DEVICE mode: round keys of THIS launch's permutation (perm_round_keys(perm_key(seed, stream, step)), host side)
     const float* eps;      // [H,B,out] or null
     int use_philox;        // FAST without eps override
     unsigned long long seed, stream_id;
@@ -166,14 +166,6 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + (c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
 #pragma unroll
     for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
-    // accumulators start at the bias (C input of the first MFMA) instead of zero: no add in the epilogue
-#pragma unroll
-    for (int ct = 0; ct < CTn; ++ct)
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[ct][r] = CT > 0 ? bv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
-
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
         const char* Wk = Wb + (size_t)kk * 1024;
 #pragma unroll
@@ -239,6 +231,15 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // scheduler sinks each load group down to its first use and the pipeline degenerates to load->wait->compute.
     GemmFrags<R, CT, EX> f0, f1;
     load(f0, 0);
+    // accumulators start at the bias (C input of the first MFMA) instead of zero: no add in the epilogue.  Initialised AFTER
+    // chunk 0's fragment loads were issued: the bias loads are older, so waiting for them leaves the fragments in flight
+    // (initialising first serialised two L2 round trips per layer: ~1.2k cycles of "set-up" per layer in the phase profile)
+#pragma unroll
+    for (int ct = 0; ct < CTn; ++ct)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[ct][r] = CT > 0 ? bv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
     prof.mark(14);
     const int last = KC - 1;
     int kk = 0;
@@ -489,7 +490,7 @@ struct RolloutSmem {
     int* term;       // [ROWS]
     int* rowid;      // [ROWS] global row id (candidate*P + particle) or -1
     double* nmean;   // [in_dim] normaliser stats (f64 like the reference)
-    double* nstd;    // [in_dim]
+    double* nstd;    // [in_dim] (f64 normaliser: holds 1 / std)
     float* minlv;    // [lv_rows][out_dim]
     float* maxlv;    // [lv_rows][out_dim]
     int* nodelta;    // [obs_dim]
@@ -584,44 +585,75 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // unbalanced member maps (BasicEnsemble) pad every member's slots with -1 at the tail: nothing to do here
         if (perm && perm[(long long)domain * ra.rows_per_domain + j0] < 0) return;
         // DEVICE mode: the step's permutation is a keyed bijection evaluated on the fly (common.hpp perm_apply)
-        const unsigned long long pkey = ra.perm_n ? perm_key(ra.seed, ra.stream_id, ra.perm_fixed ? 0xFFFFFFFFu : (unsigned)ra.t_begin) : 0ull;
         for (int s = tid; s < ROWS; s += kThreads) {
             const int j = j0 + s;
             int rid = -1;
             if (j < ra.rows_per_domain) {
                 const int jj = domain * ra.rows_per_domain + j;
-                rid = perm ? (int)perm[jj] : (ra.perm_n ? (int)perm_apply((unsigned)jj, ra.perm_n, ra.perm_a, ra.perm_b, pkey) : jj);
+                rid = perm ? (int)perm[jj] : (ra.perm_n ? (int)perm_apply((unsigned)jj, ra.perm_n, ra.perm_a, ra.perm_b, ra.perm_keys) : jj);
             }
             sm.rowid[s] = rid;
         }
     }
-    if (md.normalizer != HIPETS_NORM_NONE)
-        for (int i = tid; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = md.norm_std[i]; }
-    if (!md.deterministic)
-        for (int i = tid; i < md.lv_rows * md.out_dim; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
-    for (int i = tid; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
-    for (int i = tid; i < md.n_layers; i += kThreads) sm.lmeta[i] = md.layers[i];
+    {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
+        // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
+        const int nlv = md.deterministic ? 0 : md.lv_rows * md.out_dim;
+        const bool norm = md.normalizer != HIPETS_NORM_NONE;
+        double c_nm = 0.0, c_ns = 1.0;
+        float c_lo = 0.f, c_hi = 0.f;
+        int c_nd = 0, c_lm = 0;
+        constexpr int kMetaWords = (int)(sizeof(LayerMeta) / sizeof(int));  // the layer table travels as plain 32-bit words
+        const int n_meta = md.n_layers * kMetaWords;                        // (<= 48: one word per thread, no private copy)
+        if (norm && tid < md.in_dim) { c_nm = md.norm_mean[tid]; c_ns = md.norm_std[tid]; }
+        if (tid < nlv) { c_lo = md.min_lv[tid]; c_hi = md.max_lv[tid]; }
+        if (tid < md.obs_dim) c_nd = md.no_delta[tid];
+        if (tid < n_meta) c_lm = reinterpret_cast<const int*>(md.layers)[tid];
+        if (norm && tid < md.in_dim) { sm.nmean[tid] = c_nm; sm.nstd[tid] = md.normalizer == HIPETS_NORM_F64 ? 1.0 / c_ns : c_ns; }  // f64: 1 / std, see build_input
+        if (tid < nlv) { sm.minlv[tid] = c_lo; sm.maxlv[tid] = c_hi; }
+        if (tid < md.obs_dim) sm.nodelta[tid] = c_nd;
+        if (tid < n_meta) reinterpret_cast<int*>(sm.lmeta)[tid] = c_lm;
+        if (norm)
+            for (int i = tid + kThreads; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = md.normalizer == HIPETS_NORM_F64 ? 1.0 / md.norm_std[i] : md.norm_std[i]; }
+        for (int i = tid + kThreads; i < nlv; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
+        for (int i = tid + kThreads; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
+    }
     __syncthreads();
 
-    // ---- initial state ------------------------------------------------------------------------
-    for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
-        const int s = i / md.obs_dim, d = i % md.obs_dim;
-        const int rid = sm.rowid[s];
-        float v = 0.f;
-        if (fast) {
-            if (ra.init_states) v = rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f;
-            else if (ra.pop_env > 0) v = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
-            else v = ra.s0[d];
+    // ---- initial state, totals, flags: loads issued in batches of kStage per thread (one round trip, not one per element) ----
+    auto load_initial_state = [&]() __attribute__((always_inline)) {
+        constexpr int kStage = 4;
+        const int n_st = ROWS * md.obs_dim;
+        for (int base = tid; base < n_st; base += kStage * kThreads) {
+            float v[kStage];
+#pragma unroll
+            for (int q = 0; q < kStage; ++q) {
+                const int i = base + q * kThreads;
+                v[q] = 0.f;
+                if (i < n_st) {
+                    const int s = i / md.obs_dim, d = i - s * md.obs_dim;
+                    const int rid = sm.rowid[s];
+                    if (fast) {
+                        if (ra.init_states) v[q] = rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f;
+                        else if (ra.pop_env > 0) v[q] = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
+                        else v[q] = ra.s0[d];
+                    } else if (rid >= 0) {
+                        v[q] = ra.state[(size_t)rid * md.obs_dim + d];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kStage; ++q) {
+                const int i = base + q * kThreads;
+                if (i < n_st) sm.state[i] = v[q];
+            }
         }
-        else if (rid >= 0) v = ra.state[(size_t)rid * md.obs_dim + d];
-        sm.state[i] = v;
-    }
-    for (int s = tid; s < ROWS; s += kThreads) {
-        const int rid = sm.rowid[s];
-        sm.tot[s] = (!fast && rid >= 0) ? ra.totals[rid] : 0.f;
-        sm.term[s] = (!fast && rid >= 0) ? (int)ra.term[rid] : 0;
-        sm.lrew[s] = 0.f;
-    }
+        for (int s = tid; s < ROWS; s += kThreads) {
+            const int rid = sm.rowid[s];
+            sm.tot[s] = (!fast && rid >= 0) ? ra.totals[rid] : 0.f;
+            sm.term[s] = (!fast && rid >= 0) ? (int)ra.term[rid] : 0;
+            sm.lrew[s] = 0.f;
+        }
+    };
 
     const int nblk = (md.out_dim + 3) / 4;
     const int Kp0 = md.Kp0;
@@ -694,7 +726,11 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 } else {
                     x = actn_t[s * md.act_dim + (cc - md.obs_in)];
                 }
-                if constexpr (NORM == HIPETS_NORM_F64) x = (float)(((double)x - sm.nmean[cc]) / sm.nstd[cc]);
+                // f64 normaliser: (x - mean) * (1 / std) with the reciprocal formed once per launch in f64.  Against the reference's
+                // f64 division the product is off by <= 1.5 ulp OF F64 before the rounding to f32: the f32 value differs (by one
+                // f32 ulp) only when the quotient sits within ~2^-29 of a rounding boundary, ~1e-8 of the elements -- far inside
+                // T1 -- and the per-element f64 division sequence (~12 f64 instructions) leaves the per-step critical path
+                if constexpr (NORM == HIPETS_NORM_F64) x = (float)(((double)x - sm.nmean[cc]) * sm.nstd[cc]);
                 else if constexpr (NORM == HIPETS_NORM_F32) x = (x - (float)sm.nmean[cc]) / (float)sm.nstd[cc];
                 v[q] = (c < md.in_dim && valid) ? x : 0.f;
             }
@@ -722,10 +758,11 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     };
 
-    __syncthreads();
-    {
+    {   // the first step's actions are in flight while the state / totals / flags are fetched: one round trip for all of it
+        // (the per-step launches of EXACT / DEVICE mode pay this prologue every step)
         float av[kPrefetch];
         fetch_actions_issue(ra.t_begin, av);
+        load_initial_state();
         fetch_actions_commit(ra.t_begin, av);
     }
     __syncthreads();
@@ -734,6 +771,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     prof.mark(0);
 
     for (int t = ra.t_begin; t < ra.t_end; ++t) {
+        const bool more = t + 1 < ra.t_end;
+        float av[kPrefetch];
+        if (more) fetch_actions_issue(t + 1, av);  // consumed after the sampling phase: the HBM / L2 latency hides behind the MLP
         const int n_run = expectation ? md.M : 1;
         float* result = nullptr;
         int member = 0;
@@ -777,9 +817,6 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
         // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
         // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
-        const bool more = t + 1 < ra.t_end;
-        float av[kPrefetch];
-        if (more) fetch_actions_issue(t + 1, av);  // HBM latency hides behind this phase
         auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
             constexpr bool EXPECT = decltype(expect_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;

@@ -81,7 +81,7 @@ __global__ void export_perms_kernel(long long* out, int H, unsigned n, unsigned 
     if (i >= (long long)H * n) return;
     const int t = (int)(i / n);
     const unsigned j = (unsigned)(i % n);
-    out[i] = (long long)perm_apply(j, n, a, b, perm_key(seed, stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t));
+    out[i] = (long long)perm_apply(j, n, a, b, perm_round_keys(perm_key(seed, stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t)));
 }
 
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:

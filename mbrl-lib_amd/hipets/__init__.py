@@ -18,6 +18,8 @@ from .engine import Engine  # noqa: F401
 from .planning import (  # noqa: F401
     Agent,
     BatchedCEMAgent,
+    BatchedICEMAgent,
+    BatchedMPPIAgent,
     CEMOptimizer,
     HipTrajectoryEvalFn,
     ICEMOptimizer,
@@ -32,6 +34,13 @@ from .planning import (  # noqa: F401
     create_trajectory_optim_agent_for_model,
     get_engine,
     make_eval_fn,
+)
+from .propagation import (  # noqa: F401
+    propagate,
+    propagate_expectation,
+    propagate_fixed_model,
+    propagate_from_indices,
+    propagate_random_model,
 )
 from . import dist  # noqa: F401
 

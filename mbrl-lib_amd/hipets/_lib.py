@@ -117,6 +117,10 @@ SYMBOLS = {
     "hipets_plan_cem_batched": (C.c_int, [_P, C.POINTER(CemParams), C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_plan_mppi": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int32,
                                    C.c_uint64, C.c_uint64, _P]),
+    "hipets_plan_mppi_batched": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _P, _P, _P, _P,
+                                           C.c_int32, C.c_uint64, C.c_uint64, _P]),
+    "hipets_plan_icem_batched": (C.c_int, [_P, C.POINTER(IcemParams), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64,
+                                           C.c_uint64, _P, _P]),
     "hipets_plan_icem": (C.c_int, [_P, C.POINTER(IcemParams), _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64, C.c_uint64,
                                    _P, _P]),
     "hipets_comm_unique_id": (C.c_int, [_P]),

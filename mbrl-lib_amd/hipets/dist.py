@@ -87,3 +87,26 @@ def init_engine_comm(engine, group=None):
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     engine.comm_init(box[0], rank, world)
     return engine
+
+
+def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, seed: int = 0, plan_id: int = 0):
+    """``Engine.plan_cem_sharded`` with the failure policy of SURVEY.md section 5: if the engine has no communicator, or RCCL
+    reports an error while the sharded plan is enqueued, warn and plan the WHOLE population on this GPU alone
+    (``hipets_plan_cem``: same sampler streams, so every rank that falls back still returns a valid plan for its
+    observation) instead of failing the control loop.  Returns ``(plan, used_fallback)``."""
+    import warnings
+
+    from ._lib import HipetsError
+
+    if engine.comm_world > 1:
+        try:
+            return engine.plan_cem_sharded(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), False
+        except HipetsError as exc:
+            if "RCCL" not in str(exc) and "communicator" not in str(exc):
+                raise
+            warnings.warn(f"hipets: sharded plan failed ({exc}); falling back to a single-GPU plan on rank {engine.comm_rank}")
+            try:
+                engine.comm_destroy()
+            except HipetsError:
+                engine.comm_world, engine.comm_rank = 1, 0
+    return engine.plan_cem(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), engine.comm_world <= 1

@@ -142,8 +142,9 @@ class Engine:
                 rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
                 phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1,
                 members: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``members`` (EXACT mode, BasicEnsemble models): int64 [H, B] (random_model) or [B] (fixed_model) member of every
-        row, i.e. the reference's ``torch.randint`` draws (basic_ensemble.py:122-129, 255-260)."""
+        """``members`` (EXACT mode): int64 [H, B] (random_model) or [B] (fixed_model) active-member slot of every row: the
+        reference's ``torch.randint`` draws for BasicEnsemble models (basic_ensemble.py:122-129, 255-260), or any
+        ``propagate_from_indices``-style assignment (util/math.py:180-196) for GaussianMLP models (no batch % members rule)."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -167,8 +168,8 @@ class Engine:
         if mode == "device" and (perms is not None or eps is not None or members is not None):
             raise ValueError("mode='device' draws its permutations and eps in-kernel: perms / eps / members must be None")
         if members is not None:
-            if self.spec.ensemble_kind != "basic_ensemble" or mode != "exact" or perms is not None:
-                raise ValueError("members= is the EXACT-mode input of BasicEnsemble models (GaussianMLP takes perms=)")
+            if mode != "exact" or perms is not None:
+                raise ValueError("members= (explicit per-row member maps) is an EXACT-mode input, exclusive with perms=")
             want = (B,) if self.spec.propagation == "fixed_model" else (H, B)
             if tuple(members.shape) != want:
                 raise ValueError(f"members must have shape {want}")
@@ -233,8 +234,8 @@ class Engine:
                 raise ValueError("mode='device' draws its permutation and eps in-kernel")
         elif mode == "exact":
             if members is not None:
-                if self.spec.ensemble_kind != "basic_ensemble" or perm is not None or tuple(members.shape) != (B,):
-                    raise ValueError("members= must be int64 [B] and the model a BasicEnsemble (GaussianMLP takes perm=)")
+                if perm is not None or tuple(members.shape) != (B,):
+                    raise ValueError("members= must be int64 [B], exclusive with perm=")
                 perm, o.rows_per_member = member_slots(members.reshape(1, B), len(self.spec.members), dev)
                 o.perms = _ptr(perm)
             elif perm is not None:
@@ -299,9 +300,10 @@ class Engine:
         _lib.check(self._lib.hipets_set_plan_mode(self._h, _lib.MODES[mode]))
         self.plan_mode = mode
 
-    def set_plan_trace(self, iters: int = 0, max_rows: int = 0, horizon: int = 0, act_dim: int = 0, elite_num: int = 0):
+    def set_plan_trace(self, iters: int = 0, max_rows: int = 0, horizon: int = 0, act_dim: int = 0, elite_num: int = 0, n_env: int = 1):
         """Record the following fused plans iteration by iteration (hipets_set_plan_trace); returns the dict of device
-        tensors the library writes into.  ``iters=0`` switches recording off."""
+        tensors the library writes into.  ``iters=0`` switches recording off.  ``max_rows`` counts the candidates of ALL
+        environments of a batched plan."""
         if iters <= 0:
             _lib.check(self._lib.hipets_set_plan_trace(self._h, None))
             self._trace = None
@@ -309,9 +311,10 @@ class Engine:
         dev = self.device
         tr = {"populations": torch.zeros(iters, max_rows, horizon, act_dim, device=dev),
               "values": torch.zeros(iters, max_rows, device=dev),
-              "mus": torch.zeros(iters, horizon, act_dim, device=dev),
-              "dispersions": torch.zeros(iters, horizon, act_dim, device=dev),
-              "elite_idx": torch.zeros(iters, max(1, elite_num), dtype=torch.int32, device=dev)}
+              "mus": torch.zeros((iters, horizon, act_dim) if n_env == 1 else (iters, n_env, horizon, act_dim), device=dev),
+              "dispersions": torch.zeros((iters, horizon, act_dim) if n_env == 1 else (iters, n_env, horizon, act_dim), device=dev),
+              "elite_idx": torch.zeros((iters, max(1, elite_num)) if n_env == 1 else (iters, n_env, max(1, elite_num)), dtype=torch.int32,
+                                       device=dev)}
         t = PlanTrace()
         t.populations, t.values, t.mus = tr["populations"].data_ptr(), tr["values"].data_ptr(), tr["mus"].data_ptr()
         t.dispersions, t.elite_idx, t.max_rows = tr["dispersions"].data_ptr(), tr["elite_idx"].data_ptr(), int(max_rows)
@@ -443,48 +446,51 @@ class Engine:
         return out
 
     def plan_mppi(self, pop: int, H: int, A: int, num_iterations: int, gamma: float, beta: float, mean: torch.Tensor, lower,
-                  upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0) -> torch.Tensor:
-        """Whole MPPI plan on the device (hipets_plan_mppi).  ``mean`` [H, A] is the optimizer's persistent mean: shifted
-        and refined IN PLACE; returned for convenience."""
+                  upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0, n_env: int = 1) -> torch.Tensor:
+        """Whole MPPI plan on the device (hipets_plan_mppi[_batched]).  ``mean`` [H, A] ([n_env, H, A] for a batch of
+        environments, ``s0`` then [n_env, obs_dim]) is the optimizer's persistent mean: shifted and refined IN PLACE."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
-        for n_, t in (("mean", mean), ("lower", lower), ("upper", upper)):
+        _check_dev(mean, torch.float32, dev, "mean", numel=n_env * H * A)
+        for n_, t in (("lower", lower), ("upper", upper)):
             _check_dev(t, torch.float32, dev, n_, (H, A))
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
-        if s0.shape[0] != self.spec.obs_dim:
-            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        if s0.shape[0] != self.spec.obs_dim * n_env:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {n_env} x {self.spec.obs_dim}")
         with torch.cuda.device(dev):
-            _lib.check(self._lib.hipets_plan_mppi(self._h, pop, H, A, num_iterations, float(gamma), float(beta), _ptr(mean), _ptr(lower),
-                                                  _ptr(upper), s0.ctypes.data_as(C.c_void_p), num_particles,
-                                                  int(seed) & (2**64 - 1), int(plan_id) & (2**64 - 1), _stream(dev)))
+            _lib.check(self._lib.hipets_plan_mppi_batched(self._h, pop, H, A, num_iterations, float(gamma), float(beta), int(n_env), _ptr(mean),
+                                                          _ptr(lower), _ptr(upper), s0.ctypes.data_as(C.c_void_p), num_particles,
+                                                          int(seed) & (2**64 - 1), int(plan_id) & (2**64 - 1), _stream(dev)))
         return mean
 
     def plan_icem(self, p: "_lib.IcemParams", x0, lower, upper, elite: torch.Tensor, has_elite: bool, s0: np.ndarray,
                   num_particles: int, seed: int = 0, plan_id: int = 0, keep_idx: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Whole iCEM plan on the device (hipets_plan_icem).  ``elite`` [elite_num, H, A] is the optimizer's persistent
-        elite set (read when ``has_elite``, always overwritten); ``keep_idx`` int32 [num_iterations, keep] optionally
-        injects the kept-elite draws."""
+                  out: Optional[torch.Tensor] = None, n_env: int = 1) -> torch.Tensor:
+        """Whole iCEM plan on the device (hipets_plan_icem[_batched]).  ``elite`` [elite_num, H, A] is the optimizer's
+        persistent elite set (read when ``has_elite``, always overwritten); ``keep_idx`` int32 [num_iterations, keep]
+        optionally injects the kept-elite draws.  n_env > 1: x0 / out [n_env, H, A], elite [n_env, elite_num, H, A],
+        keep_idx [num_iterations, n_env, keep], s0 [n_env, obs_dim]."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
         shp = (p.horizon, p.act_dim)
-        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+        _check_dev(x0, torch.float32, dev, "x0", numel=n_env * p.horizon * p.act_dim)
+        for n_, t in (("lower", lower), ("upper", upper)):
             _check_dev(t, torch.float32, dev, n_, shp)
-        _check_dev(elite, torch.float32, dev, "elite", (p.elite_num,) + shp)
+        _check_dev(elite, torch.float32, dev, "elite", numel=n_env * p.elite_num * p.horizon * p.act_dim)
         if keep_idx is not None:
-            _check_dev(keep_idx, torch.int32, dev, "keep_idx", (p.num_iterations, p.keep_elite_size))
+            _check_dev(keep_idx, torch.int32, dev, "keep_idx", numel=p.num_iterations * n_env * p.keep_elite_size)
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
-        if s0.shape[0] != self.spec.obs_dim:
-            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        if s0.shape[0] != self.spec.obs_dim * n_env:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {n_env} x {self.spec.obs_dim}")
         if out is None:
-            out = torch.empty(shp, dtype=torch.float32, device=dev)
+            out = torch.empty(tuple(x0.shape), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(self._lib.hipets_plan_icem(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper), _ptr(elite),
-                                                  int(bool(has_elite)), _ptr(keep_idx) if keep_idx is not None else None,
-                                                  s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
-                                                  int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+            _lib.check(self._lib.hipets_plan_icem_batched(self._h, C.byref(p), int(n_env), _ptr(x0), _ptr(lower), _ptr(upper), _ptr(elite),
+                                                          int(bool(has_elite)), _ptr(keep_idx) if keep_idx is not None else None,
+                                                          s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                          int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
         return out
 
     # ---- in-library RCCL communicator (population-sharded fused plans) -----------------------------
@@ -582,7 +588,8 @@ class Engine:
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------------
-    def timing_enable(self, on: bool = True):
+    def timing_enable(self, on=True):
+        """True / 1: time every rollout-kernel launch; k > 1: every k-th launch; False / 0: off."""
         _lib.check(self._lib.hipets_timing_enable(self._h, int(on)))
 
     def timing_read(self, reset: bool = True):

@@ -110,10 +110,32 @@ class ModelSpec:
             raise UnsupportedModelError("model out_size inconsistent with obs_dim / learned_rewards")
 
 
-def _fn_name(fn) -> Optional[str]:
+_CLOSED_FORM_MODULES = {"reward": "mbrl.env.reward_fns", "termination": "mbrl.env.termination_fns"}
+_OBS_PROCESS_FNS = {("mbrl.env.pets_halfcheetah", "HalfCheetahEnv.preprocess_fn"): "halfcheetah",
+                    ("mbrl.env.pets_cartpole", "CartPoleEnv.preprocess_fn"): "cartpole_pets"}
+
+
+def _closed_form(fn, kind: str, known) -> Optional[str]:
+    """Name of the mbrl.env closed form ``fn`` IS, or None.  A function is recognised by where it is defined
+    (``mbrl.env.reward_fns.halfcheetah`` ...), never by its bare name: a user function that happens to be called
+    ``halfcheetah`` must not be replaced by the built-in formula.  Anything else may opt in explicitly with an attribute
+    ``hipets_closed_form = "<name>"`` (tests and duck-typed models do)."""
     if fn is None:
         return None
-    return getattr(fn, "__name__", None)
+    tag = getattr(fn, "hipets_closed_form", None)
+    if tag is not None:
+        return tag if tag in known else None
+    name = getattr(fn, "__name__", None)
+    if getattr(fn, "__module__", None) == _CLOSED_FORM_MODULES[kind] and name in known:
+        return name
+    return None
+
+
+def _obs_process_name(fn) -> Optional[str]:
+    tag = getattr(fn, "hipets_closed_form", None)
+    if tag is not None:
+        return tag if tag in ("halfcheetah", "cartpole_pets") else None
+    return _OBS_PROCESS_FNS.get((getattr(fn, "__module__", None), getattr(fn, "__qualname__", None)))
 
 
 def _read_gaussian_mlp(mlp):
@@ -178,23 +200,25 @@ def spec_from_model_env(model_env, obs_dim: Optional[int] = None, act_dim: Optio
     obs_fn = getattr(dm, "obs_process_fn", None)
     obs_process = "none"
     if obs_fn is not None:
-        q = getattr(obs_fn, "__qualname__", "")
-        if "HalfCheetahEnv" in q:
-            obs_process = "halfcheetah"
-        elif "CartPoleEnv" in q:
-            obs_process = "cartpole_pets"
-        else:
-            raise UnsupportedModelError(f"obs_process_fn {q!r} has no fused implementation")
+        obs_process = _obs_process_name(obs_fn)
+        if obs_process is None:
+            raise UnsupportedModelError(f"obs_process_fn {getattr(obs_fn, '__qualname__', obs_fn)!r} has no fused implementation")
     od = obs_dim if obs_dim is not None else int(model_env.observation_space.shape[0])
     ad = act_dim if act_dim is not None else int(model_env.action_space.shape[0])
-    rew = model_env.reward_fn
-    rew_name, term_name = _fn_name(rew), _fn_name(model_env.termination_fn)
+    rew, term = model_env.reward_fn, model_env.termination_fn
+    # model_env.py:124-128: a reward_fn that is not None ALWAYS wins over the learned reward, so an unrecognised callable
+    # is never mapped to "learned" -- it is either kept for the unfused path or rejected
+    rew_name = None if rew is None else _closed_form(rew, "reward", _KNOWN_REWARDS)
+    term_name = _closed_form(term, "termination", _KNOWN_TERMS)
     custom_rew = custom_term = None
-    if allow_custom_fns:
-        if rew is not None and rew_name not in _KNOWN_REWARDS:
-            custom_rew, rew_name = rew, "none"
-        if term_name not in _KNOWN_TERMS:
-            custom_term, term_name = model_env.termination_fn, "no_termination"
+    if rew is not None and rew_name is None:
+        if not allow_custom_fns:
+            raise UnsupportedModelError(f"reward_fn {getattr(rew, '__qualname__', rew)!r} is not one of mbrl.env.reward_fns' closed forms")
+        custom_rew, rew_name = rew, "none"
+    if term_name is None:
+        if not allow_custom_fns:
+            raise UnsupportedModelError(f"termination_fn {getattr(term, '__qualname__', term)!r} is not one of mbrl.env.termination_fns' closed forms")
+        custom_term, term_name = term, "no_termination"
     spec = ModelSpec(
         weights=ws, biases=bs, obs_dim=od, act_dim=ad,
         min_logvar=lv_lo, max_logvar=lv_hi, ensemble_kind=ensemble_kind,
@@ -219,7 +243,9 @@ def model_version(model_env) -> tuple:
     mlp = dm.model
     vers = tuple(int(p._version) for p in mlp.parameters())
     norm = getattr(dm, "input_normalizer", None)
-    nid = (id(norm.mean), id(norm.std)) if norm is not None else ()
+    # the stats are re-assigned tensors (util/math.py:120-127): (storage address, in-place version) of the LIVE tensors, which
+    # the spec keeps referenced, so an address cannot be recycled while it is the recorded one
+    nid = tuple((int(t.data_ptr()), int(t._version)) for t in (norm.mean, norm.std)) if norm is not None else ()
     el = tuple(mlp.elite_models) if getattr(mlp, "elite_models", None) is not None else None
     return (vers, nid, el, getattr(mlp, "propagation_method", None))
 

@@ -1006,6 +1006,101 @@ class BatchedCEMAgent(Agent):
         return self.plan(obs_batch)[:, 0]
 
 
+class BatchedMPPIAgent(Agent):
+    """Batched planning with MPPI: ``MPPIOptimizer.optimize`` (trajectory_opt.py:238-311) for ``n_env``
+    environments in one set of launches (hipets_plan_mppi_batched).  Every environment keeps its own persistent mean,
+    shifted one step per plan like the reference's (Appendix B4-B6)."""
+
+    def __init__(self, eval_fn: HipTrajectoryEvalFn, n_env: int, action_lb: Sequence[float], action_ub: Sequence[float],
+                 planning_horizon: int, num_iterations: int, population_size: int, gamma: float, sigma: float, beta: float,
+                 seed: int = 0):
+        if eval_fn.mode != "fast":
+            raise ValueError("batched planning runs the FAST rollout path")
+        self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
+        self.n_env, self.horizon = int(n_env), int(planning_horizon)
+        lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)
+        self.act_dim = int(lb.shape[0])
+        self.lower = torch.tensor(np.tile(lb, (planning_horizon, 1)), device=self.device).contiguous()
+        self.upper = torch.tensor(np.tile(ub, (planning_horizon, 1)), device=self.device).contiguous()
+        self.mean = torch.zeros(self.n_env, self.horizon, self.act_dim, device=self.device)
+        self.refinements, self.population_size, self.gamma, self.sigma, self.beta = int(num_iterations), int(population_size), gamma, sigma, beta
+        self.seed, self.calls = int(seed), 0
+
+    def plan(self, obs_batch: np.ndarray, **_kwargs) -> np.ndarray:
+        obs_batch = np.asarray(obs_batch, dtype=np.float32)
+        assert obs_batch.shape[0] == self.n_env
+        _prepare_fused(self.eval_fn, [self.population_size])
+        self.calls += 1
+        self.engine.plan_mppi(self.population_size, self.horizon, self.act_dim, self.refinements, self.gamma, self.beta, self.mean,
+                              self.lower, self.upper, obs_batch, self.eval_fn.num_particles, seed=self.seed ^ self.eval_fn.seed,
+                              plan_id=self.calls, n_env=self.n_env)
+        return self.mean.cpu().numpy()
+
+    def act(self, obs_batch: np.ndarray, **_kwargs) -> np.ndarray:
+        return self.plan(obs_batch)[:, 0]
+
+
+class BatchedICEMAgent(Agent):
+    """Batched planning with iCEM: ``ICEMOptimizer.optimize`` (trajectory_opt.py:391-487) for ``n_env``
+    environments in one set of launches (hipets_plan_icem_batched): per-environment mean / variance / persistent elites,
+    warm start shifted by ``replan_freq`` per environment (trajectory_opt.py:563-567)."""
+
+    def __init__(self, eval_fn: HipTrajectoryEvalFn, n_env: int, action_lb: Sequence[float], action_ub: Sequence[float],
+                 planning_horizon: int, num_iterations: int, elite_ratio: float, population_size: int, population_decay_factor: float,
+                 colored_noise_exponent: float, keep_elite_frac: float, alpha: float, return_mean_elites: bool = True,
+                 population_size_module: Optional[int] = None, replan_freq: int = 1, seed: int = 0):
+        if eval_fn.mode != "fast":
+            raise ValueError("batched planning runs the FAST rollout path")
+        self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
+        self.n_env, self.horizon, self.replan_freq = int(n_env), int(planning_horizon), int(replan_freq)
+        lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)
+        A = int(lb.shape[0])
+        self.lower = torch.tensor(np.tile(lb, (planning_horizon, 1)), device=self.device).contiguous()
+        self.upper = torch.tensor(np.tile(ub, (planning_horizon, 1)), device=self.device).contiguous()
+        self.initial_solution = torch.tensor((lb + ub) / 2, device=self.device).repeat(self.n_env, planning_horizon, 1).contiguous()
+        self.previous_solution = self.initial_solution.clone()
+        # sizes exactly as ICEMOptimizer computes them (:363-389)
+        self._opt = ICEMOptimizer(num_iterations, elite_ratio, population_size, population_decay_factor, colored_noise_exponent,
+                                  self.lower.tolist(), self.upper.tolist(), keep_elite_frac, alpha, self.device,
+                                  return_mean_elites=return_mean_elites, population_size_module=population_size_module, seed=seed)
+        K, keep = int(self._opt.elite_num), int(self._opt.keep_elite_size)
+        self._params = IcemParams(population_size=int(population_size), horizon=self.horizon, act_dim=A, num_iterations=int(num_iterations),
+                                  elite_num=K, keep_elite_size=keep, population_size_module=int(population_size_module or 0),
+                                  return_mean_elites=int(bool(return_mean_elites)), alpha=float(alpha),
+                                  population_decay_factor=float(population_decay_factor), colored_noise_exponent=float(colored_noise_exponent))
+        self.elite = torch.empty(self.n_env, K, self.horizon, A, device=self.device)
+        self.has_elite = False
+        self.seed, self.calls = int(seed), 0
+
+    def reset(self):
+        self.previous_solution = self.initial_solution.clone()  # the elites persist, like ICEMOptimizer.elite (Appendix B6)
+
+    def plan(self, obs_batch: np.ndarray, keep_idx: Optional[torch.Tensor] = None, **_kwargs) -> np.ndarray:
+        obs_batch = np.asarray(obs_batch, dtype=np.float32)
+        assert obs_batch.shape[0] == self.n_env
+        o, iters = self._opt, self._params.num_iterations
+        sizes = []
+        for i in range(iters):
+            extra = 0
+            if self.has_elite or i > 0:
+                extra = 1 if (i == iters - 1 and i != 0) else int(o.keep_elite_size)
+            sizes.append(o._iteration_size(i) + extra)
+        _prepare_fused(self.eval_fn, sizes)
+        self.calls += 1
+        best = self.engine.plan_icem(self._params, self.previous_solution, self.lower, self.upper, self.elite, self.has_elite, obs_batch,
+                                     self.eval_fn.num_particles, seed=self.seed ^ self.eval_fn.seed, plan_id=self.calls, keep_idx=keep_idx,
+                                     n_env=self.n_env)
+        if iters > 0:
+            self.has_elite = True
+        self.previous_solution = best.roll(-self.replan_freq, dims=1)
+        self.previous_solution[:, -self.replan_freq:] = self.initial_solution[:, :1]
+        self.previous_solution = self.previous_solution.contiguous()
+        return best.cpu().numpy()
+
+    def act(self, obs_batch: np.ndarray, **_kwargs) -> np.ndarray:
+        return self.plan(obs_batch)[:, 0]
+
+
 def complete_agent_cfg(env, agent_cfg):
     """The subset of mbrl/planning/core.py:71-123 a trajectory-optimizer agent config needs: fill
     ``action_lb`` / ``action_ub`` placeholders ("???") from the action space.  Works on plain dicts and on

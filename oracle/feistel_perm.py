@@ -1,5 +1,5 @@
 """Test infrastructure: a numpy restatement of the device-side random permutation of DEVICE-mode rollouts
-(mbrl-lib_amd/csrc/common.hpp: perm_radices / perm_hash / perm_mix64 / perm_key / perm_apply).
+(mbrl-lib_amd/csrc/common.hpp: perm_radices / perm_hash / perm_mix64 / perm_key / perm_round_keys / perm_scale / perm_apply).
 
 The engine replaces the reference's per-step ``torch.randperm(B)`` (mbrl/models/gaussian_mlp.py:203-205) by a keyed
 bijection of [0, B) evaluated in-kernel.  This file restates that bijection so that (a) its statistical quality can be
@@ -56,10 +56,10 @@ def permutation(n: int, seed: int, stream: int, step: int) -> np.ndarray:
         L, R = x // np.uint64(b), x % np.uint64(b)
         for r in range(ROUNDS):
             if r & 1:
-                R = R + _hash32(L, ks[r]) % np.uint64(b)
+                R = R + ((_hash32(L, ks[r]) * np.uint64(b)) >> np.uint64(32))  # perm_scale: floor(h * b / 2^32)
                 R = np.where(R >= b, R - np.uint64(b), R)
             else:
-                L = L + _hash32(R, ks[r]) % np.uint64(a)
+                L = L + ((_hash32(R, ks[r]) * np.uint64(a)) >> np.uint64(32))
                 L = np.where(L >= a, L - np.uint64(a), L)
         x = L * np.uint64(b) + R
         done = x < n

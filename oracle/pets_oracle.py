@@ -549,6 +549,7 @@ def mppi_optimize(
     obj_fun, state: MPPIState, lower: torch.Tensor, upper: torch.Tensor, num_iterations: int,
     population_size: int, gamma: float, sigma: float, beta: float,
     noise: Optional[Sequence[torch.Tensor]] = None, record: Optional[list] = None,
+    teacher: Optional[Sequence[torch.Tensor]] = None,  # teacher[k] = mean to START refinement k + 1 from (replay aid)
 ) -> torch.Tensor:
     """MPPIOptimizer.optimize (trajectory_opt.py:238-311), quirks of Appendix B4/B5 included:
     ``past_action`` aliases ``mean[0]`` and is overwritten by the shift (:257-258); ``sigma`` only
@@ -558,6 +559,8 @@ def mppi_optimize(
     past_action = state.mean[0]  # view (:257)
     state.mean[:-1] = state.mean[1:].clone()  # :258  (past_action now == old mean[1])
     for k in range(num_iterations):
+        if teacher is not None and k > 0:
+            state.mean = teacher[k - 1].clone()
         if noise is not None:
             z = noise[k]
         else:

@@ -57,7 +57,15 @@ def main():
         torch.cuda.synchronize()
         n, ms = eng.timing_read(reset=True)
         eng.timing_enable(False)
-        out["device"][f"R{R}"] = {"kernel_us_per_step": 1e3 * ms / n, "launches": n, "rollout_ms_kernels": ms / 5, "rollout_ms_wall": e0.elapsed_time(e1) / 5}
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        for i in range(5):
+            eng.rollout(actions, s0, P, mode="device", seed=1, stream_id=2 + i, rows_per_group=R)
+        f1.record()
+        torch.cuda.synchronize()
+        out["device"][f"R{R}"] = {"kernel_us_per_step": 1e3 * ms / n, "launches": n, "rollout_ms_kernels": ms / 5, "rollout_ms_wall_events_on_every_packet": e0.elapsed_time(e1) / 5,
+                                  "rollout_ms_wall": f0.elapsed_time(f1) / 5}
     pc = torch.zeros(8, 16, dtype=torch.int64, device=dev)
     eng.rollout(actions, s0, P, mode="fast", seed=1, stream_id=99, phase_cycles=pc)
     torch.cuda.synchronize()

@@ -8,11 +8,13 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 run() { name=$1; shift; echo "== $name: $*" ; ( time timeout ${TMO:-900} "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)"; }
 run smoke python -c "import __graft_entry__ as g; g.smoke()"
-run tests_new python -m pytest tests/test_gpu_device_mode.py tests/test_gpu_plans_full_size.py -q --maxfail=30 -p no:cacheprovider
-run tests_rest python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider --deselect tests/test_gpu_device_mode.py --deselect tests/test_gpu_plans_full_size.py
+run tests python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider
 run variants_default python profiles/kernel_variants.py
-HIPETS_LIB=$PWD/mbrl-lib_amd/hipets/libhipets_mw3.so run variants_mw3 python profiles/kernel_variants.py
-run microbench ./profiles/microbench/mfma_valu_2wave
-run bench python bench.py --steps 10 --warmup 2 --cpu-budget 15
+run bench python bench.py --steps 20 --warmup 3 --cpu-budget 15
+HIPETS_DIST_BACKEND=gloo run bench_gloo2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 1
+run other_configs python profiles/other_configs.py --reps 5
+for c in cfg1_cartpole cfg4_humanoid_truncated_obs cfg4_humanoid_v4_obs376 cfg5_cheetah_run planet; do
+  run trace_$c rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -o t -- python profiles/other_configs.py --only $c --reps 5
+done
 grep -h '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json
 echo done

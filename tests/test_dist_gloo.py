@@ -65,3 +65,36 @@ def test_sharded_eval_world2_gloo(tmp_path, pop):
     v0 = torch.load(tmp_path / "v0.pt")
     v1 = torch.load(tmp_path / "v1.pt")
     assert torch.equal(v0, v1) and v0.shape[0] == pop
+
+
+def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
+    """SURVEY.md section 5 "failure detection": an RCCL error inside the sharded plan -> warn, drop the communicator, plan on
+    this GPU alone; errors that are not communication errors still propagate."""
+    import hipets
+    from hipets import dist as hdist
+
+    class FakeEngine:
+        comm_world, comm_rank = 2, 1
+        destroyed = False
+
+        def __init__(self, message):
+            self.message = message
+
+        def plan_cem_sharded(self, *a, **k):
+            raise hipets.HipetsError(self.message)
+
+        def plan_cem(self, params, x0, lower, upper, s0, P, seed=0, plan_id=0):
+            return ("single-gpu plan", seed, plan_id)
+
+        def comm_destroy(self):
+            self.destroyed = True
+            self.comm_world, self.comm_rank = 1, 0
+
+    eng = FakeEngine("RCCL error 5 (unhandled system error) at hipets.hip:1200")
+    with pytest.warns(UserWarning, match="falling back to a single-GPU plan"):
+        plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=3, plan_id=9)
+    assert plan == ("single-gpu plan", 3, 9) and fell_back and eng.destroyed and eng.comm_world == 1
+    plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=3, plan_id=10)  # no communicator any more
+    assert plan[0] == "single-gpu plan" and fell_back
+    with pytest.raises(hipets.HipetsError, match="act_dim"):
+        hdist.plan_cem_sharded(FakeEngine("act_dim 5 != model act_dim 6"), None, None, None, None, None, 20)

@@ -341,3 +341,30 @@ def test_model_env_exact_mode_basic_ensemble_replays_generator_order(engine, pro
         assert torch.allclose(nobs.cpu(), rn, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), rr, rtol=1e-5, atol=2e-6)
         assert torch.equal(done.cpu(), rd)
         x = rn
+
+
+@pytest.mark.parametrize("prop", ["random_model", "fixed_model"])
+def test_gaussian_mlp_with_explicit_member_maps(engine, prop):
+    """per-row member assignment in the sense of mbrl.util.math.propagate_from_indices
+    (util/math.py:180-196) for a GaussianMLP model -- every row evaluated by the member an arbitrary (unbalanced) index
+    tensor names, batch size NOT a multiple of the member count -- through EXACT mode's members= input, vs the oracle."""
+    obs, act, pop, P, H, E = 11, 3, 23, 3, 5, 5  # B = 69, not a multiple of 5
+    om = po.make_synthetic_model(obs, act, ensemble_size=E, hid=40, seed=31, propagation=prop)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(9)
+    B = pop * P
+    actions = torch.rand(pop, H, act, generator=g) * 2 - 1
+    s0 = (np.random.default_rng(1).standard_normal(obs) * 0.1).astype(np.float32)
+    members = torch.randint(E, (B,) if prop == "fixed_model" else (H, B), generator=g)
+    members[..., : B // 3] = 2  # unbalanced on purpose
+    eps = torch.randn(H, B, obs, generator=g)
+    ref = po.rollout(om, actions, s0, P, members=members, eps=eps)
+    out = engine.rollout(actions.to(DEV), s0, P, mode="exact", members=members, eps=eps.to(DEV))
+    assert_returns_close(out, ref)
+    # one transition, the same way
+    x = torch.randn(B, obs, generator=g) * 0.1
+    a = torch.rand(B, act, generator=g) * 2 - 1
+    m1 = members if members.ndim == 1 else members[0]
+    nobs, rew, done = engine.step(x.to(DEV), a.to(DEV), mode="exact", sample=True, members=m1, eps=eps[0].to(DEV))
+    r_nobs, r_rew, _ = po.step(om, x, a, member_of_row=m1, eps=eps[0], sample=True)
+    assert torch.allclose(nobs.cpu(), r_nobs, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), r_rew, rtol=1e-5, atol=2e-6)

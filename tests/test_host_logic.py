@@ -77,6 +77,12 @@ def no_termination(act, next_obs):
     return torch.zeros(len(next_obs), 1, dtype=torch.bool)
 
 
+# stand-ins for mbrl.env.reward_fns.halfcheetah / termination_fns.no_termination: functions defined elsewhere must opt in
+# explicitly, a bare name is not enough (see test_user_functions_with_builtin_names_are_not_silently_replaced)
+halfcheetah.hipets_closed_form = "halfcheetah"
+no_termination.hipets_closed_form = "no_termination"
+
+
 class _Space:
     def __init__(self, n):
         self.shape = (n,)
@@ -115,6 +121,82 @@ def test_spec_rejects_unknown_activation_and_python_reward():
     me.reward_fn = lambda a, o: o[:, :1]
     with pytest.raises(UnsupportedModelError):
         hipets.spec_from_model_env(me)
+
+
+def test_user_functions_with_builtin_names_are_not_silently_replaced():
+    """A user reward called `halfcheetah` (or an env class called HalfCheetahEnv) is NOT the closed form of mbrl.env:
+    recognition goes by defining module, so such models are rejected (or routed to the unfused path), never approximated."""
+    def halfcheetah(act, next_obs):  # noqa: F811  same NAME as the built-in, different function
+        return 2.0 * next_obs[:, :1]
+
+    me = _FakeModelEnv()
+    me.reward_fn = halfcheetah
+    with pytest.raises(UnsupportedModelError, match="reward_fn"):
+        hipets.spec_from_model_env(me)
+    spec = hipets.spec_from_model_env(me, allow_custom_fns=True)
+    assert spec.reward == "none" and spec.custom_reward_fn is halfcheetah
+
+    class HalfCheetahEnv:  # same class name as mbrl.env.pets_halfcheetah.HalfCheetahEnv, different preprocessing
+        @staticmethod
+        def preprocess_fn(x):
+            return x
+
+    me = _FakeModelEnv()
+    me.dynamics_model.obs_process_fn = HalfCheetahEnv.preprocess_fn
+    with pytest.raises(UnsupportedModelError, match="obs_process_fn"):
+        hipets.spec_from_model_env(me)
+    # a callable without a name (functools.partial) with learned rewards: still not "learned reward" (model_env.py:124-128)
+    import functools
+
+    me = _FakeModelEnv()
+    me.dynamics_model.learned_rewards = True
+    me.reward_fn = functools.partial(lambda scale, a, o: scale * o[:, :1], 3.0)
+    with pytest.raises(UnsupportedModelError):
+        hipets.spec_from_model_env(me)
+    # functions that really live in mbrl.env.* are recognised by module + name
+    fn = lambda a, o: o[:, :1]  # noqa: E731
+    fn.__module__, fn.__name__ = "mbrl.env.reward_fns", "halfcheetah"
+    me = _FakeModelEnv()
+    me.reward_fn = fn
+    assert hipets.spec_from_model_env(me).reward == "halfcheetah"
+
+
+class MissingMandatoryValue(Exception):
+    """Same name as omegaconf.errors.MissingMandatoryValue (omegaconf itself is not installed here)."""
+
+
+class _DictConfigLike:
+    """Behaves like an OmegaConf DictConfig where it matters: reading a key that holds "???" RAISES (it is not a KeyError),
+    assignment works, keys() lists missing keys too."""
+
+    def __init__(self, **kw):
+        self._d = dict(kw)
+
+    def keys(self):
+        return self._d.keys()
+
+    def __getitem__(self, k):
+        v = self._d[k]
+        if isinstance(v, str) and v == "???":
+            raise MissingMandatoryValue(f"Missing mandatory value: {k}")
+        return v
+
+    def __setitem__(self, k, v):
+        self._d[k] = v
+
+    def __contains__(self, k):
+        return k in self._d
+
+
+def test_stock_configs_with_missing_values_as_omegaconf_presents_them():
+    """conf/action_optimizer/cem.yaml ships `lower_bound: ???`, conf/algorithm/pets.yaml `action_lb: ???`: under OmegaConf
+    reading them raises MissingMandatoryValue.  complete_agent_cfg fills the action bounds, _instantiate drops what is
+    still missing once the overrides are applied (the reference writes the bounds into the cfg first, trajectory_opt.py:525-527)."""
+    cfg = _DictConfigLike(_target_="hipets.TrajectoryOptimizerAgent", action_lb="???", action_ub="???", planning_horizon=3)
+    complete_agent_cfg(_FakeModelEnv(), cfg)
+    assert cfg["action_lb"] == [-1.0, -1.0] and cfg["action_ub"] == [1.0, 1.0]
+    obj = _instantiate(_DictConfigLike(_target_="fractions.Fraction", numerator="???", denominator="???"), numerator=3)
+    assert obj == 3
 
 
 def test_complete_agent_cfg_fills_placeholders():

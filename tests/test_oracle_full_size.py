@@ -25,7 +25,8 @@ def oracle_agent(name, meta):
     c = FULL_CASES[name]
     obs, act, P, H = c["obs"], c["act"], c["P"], c["H"]
     om = po.make_synthetic_model(obs, act, **c["mkw"])
-    assert np.allclose(weights_checksum(om), meta["weights_checksum"], rtol=0, atol=0), "synthetic model differs from the recorded one"
+    # f64 sums over 200 k weights: the last digit depends on ATen's thread-count dependent summation order
+    assert np.allclose(weights_checksum(om), meta["weights_checksum"], rtol=1e-12, atol=0), "synthetic model differs from the recorded one"
     gen = torch.Generator().manual_seed(meta["generator_seed"])
     st = po.TrajectoryOptimizerState(-np.ones(act), np.ones(act), H)
     mppi, icem = po.MPPIState(H, act), po.ICEMState()

@@ -364,3 +364,22 @@ def test_port_plan_time_matches_the_reference_classes_on_cfg2(mbrl):
         t0 = time.perf_counter(); port_plan(); t_port.append(time.perf_counter() - t0)  # noqa: E702
     ratio = min(t_port) / min(t_ref)
     assert 0.6 < ratio < 1.5, f"port {min(t_port):.3f}s vs reference {min(t_ref):.3f}s per cfg2 plan"
+
+
+def test_propagate_helpers_equal_the_reference(mbrl):
+    """hipets.propagate* vs mbrl.util.math.propagate* (util/math.py:179-303), bitwise, same global-generator consumption."""
+    import hipets
+
+    g = torch.Generator().manual_seed(0)
+    preds = (torch.randn(5, 12, 7, generator=g), torch.randn(5, 12, 7, generator=g))
+    idx = torch.randint(5, (12,), generator=g)
+    ref = mbrl.util.math
+    assert torch.equal(hipets.propagate_from_indices(preds[0], idx), ref.propagate_from_indices(preds[0], idx))
+    for method in ("expectation", "fixed_model", "random_model"):
+        torch.manual_seed(3)
+        mine = hipets.propagate(preds, method, idx)
+        torch.manual_seed(3)
+        theirs = ref.propagate(preds, method, idx)
+        assert all(torch.equal(a, b) for a, b in zip(mine, theirs)), method
+    with pytest.raises(ValueError, match="Invalid propagation method"):
+        hipets.propagate(preds, "nope")
