@@ -132,6 +132,9 @@ typedef struct {
                              /*   row -> member assignment, no batch % members rule                                      */
     int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
                              /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
+    int32_t generic_kernel;  /* 1 = never use a shape-specialised kernel instance (the library instantiates the rollout     */
+                             /*   kernel for the BASELINE shapes with layer shapes / reward / termination fns as compile-     */
+                             /*   time facts; same arithmetic -- tests compare the two bit for bit)                           */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -369,6 +372,13 @@ typedef struct {
  * returns DEVICE [pop] particle-averaged.  One kernel launch for the whole horizon.                              */
 int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop,
                           int32_t horizon, int32_t num_particles, const hipets_planet_opts* opts, float* returns, void* stream);
+
+/* The PlaNet planner as one call: CEMOptimizer.optimize (trajectory_opt.py:142-188; the PlaNet configs use the clipped-normal
+ * branch :116-120, conf/overrides/planet_cheetah_run.yaml:29-35) with hipets_planet_rollout as objective, no host round trip.
+ * Arguments as hipets_plan_cem, with the latent start state of hipets_planet_rollout instead of an observation.            */
+int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
+                           const float* latent0, const float* belief0, int32_t num_particles, uint64_t seed, uint64_t plan_id,
+                           float* out, void* stream);
 
 /* ---- instrumentation (bench.py roofline leg) ----------------------------------------------- */
 /* on = 1: every rollout-kernel launch carries a start / stop hipEvent pair on its dispatch packet; on = k > 1: every

@@ -383,6 +383,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     }
     md.Kp0 = lms[0].Kp;
     md.hidC = up16(d->hid) / kTile;
+    md.outC = up16(md.out_total) / kTile;
     md.wmember = woff;
     md.bmember = boff;
     // row stride: >= widest activation, == 8 (mod 64) floats => conflict-free ds_read_b128 A fragments
@@ -510,6 +511,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     ra.trace_rewards = o->trace_rewards;
     ra.phase_cycles = reinterpret_cast<long long*>(o->phase_cycles);
     ra.pop_env = n_env > 1 ? pop / n_env : 0;
+    ra.generic_only = o->generic_kernel;
 
     if (o->mode == HIPETS_MODE_EXACT || o->mode == HIPETS_MODE_DEVICE) {
         // Reference propagation semantics: per step ONE balanced permutation of all B rows, slot j -> member j / (B / M)
@@ -646,6 +648,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     ra.trace_next_obs = nullptr;
     ra.trace_rewards = nullptr;
     ra.phase_cycles = nullptr;
+    ra.generic_only = o->generic_kernel;
     ra.t_begin = 0;
     ra.t_end = 1;
     if (o->mode == HIPETS_MODE_EXACT || o->mode == HIPETS_MODE_DEVICE) {
@@ -1193,6 +1196,47 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st));
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
+                           const float* latent0, const float* belief0, int32_t P, uint64_t seed, uint64_t plan_id, float* out,
+                           void* stream) {
+    if (!e || !e->has_planet) return fail("engine has no PlaNet model (call hipets_planet_set_model)");
+    if (check_cem(p)) return 1;
+    if (!x0 || !lower || !upper || !latent0 || !belief0 || !out) return fail("null argument");
+    if (p->act_dim != e->pd.action) return fail("act_dim %d != model action_size %d", p->act_dim, e->pd.action);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    const CemDev c = make_cem(p, 1);
+    const size_t nd = (size_t)c.D;
+    if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
+        e->population.ensure((size_t)c.pop * nd * 4) || e->values.ensure((size_t)c.pop * 4))
+        return 1;
+    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
+                       e->disp.as<float>(), e->best_value.as<float>());
+    HCHECK(hipGetLastError());
+    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
+    hipets_planet_opts po{};
+    po.seed = seed;
+    int n2 = 1;
+    while (n2 < c.pop) n2 <<= 1;
+    for (int i = 0; i < p->num_iterations; ++i) {
+        const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
+        const long long n = (long long)c.pop * c.D;
+        hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
+                           lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid, e->population.as<float>());
+        HCHECK(hipGetLastError());
+        po.stream_id = sid;
+        if (hipets_planet_rollout(e, e->population.as<float>(), latent0, belief0, c.pop, c.H, P, &po, e->values.as<float>(), stream)) return 1;
+        int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+                           e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                           e->best_solution.as<float>(), eidx);
+        HCHECK(hipGetLastError());
+        if (trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st)) return 1;
+    }
+    HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -45,7 +45,8 @@ struct ModelDev {
     int propagation, deterministic, obs_process, reward_fn, term_fn, target_is_delta, learned_rewards, normalizer;
     const LayerMeta* layers;  // DEVICE [n_layers] (a table in memory: runtime-indexed kernargs would go to scratch)
     int Kp0;                  // padded input width of layer 0
-    int hidC;                 // column tiles of a hidden layer (cost model)
+    int hidC;                 // column tiles of a hidden layer (cost model; shape of the lean kernel instances)
+    int outC;                 // column tiles of the output layer
     long long wmember;  // floats per member (packed weights)
     int bmember;        // floats per member (padded biases)
     int ld;             // LDS activation row stride in floats (== 8 mod 64)
@@ -85,6 +86,7 @@ struct RolloutArgs {
     int pop_env;               // FAST batched planning: candidates per environment (candidate c starts from s0[c / pop_env]); 0 = one env
     const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
     int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
+    int generic_only;          // never pick a shape-specialised (lean) kernel instance (hipets_rollout_opts.generic_kernel)
 };
 
 // D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
@@ -103,10 +105,12 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memo
 // {16kk + 4s + g : s = 0..3} with ONE ds_read_b128 at [16kk + 4g, +3].
 __device__ __forceinline__ int lds_col(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }
 
-// phase profiler: lane 0 of every wave of workgroup 0 accumulates s_memtime deltas per phase into
-// RolloutArgs::phase_cycles[wave][phase] (a profiling aid, off unless the caller passes a buffer)
+// phase profiler: lane 0 of every wave of workgroup 0 accumulates s_memtime deltas per phase in LDS (a mark is one LDS
+// read-modify-write on one lane, ~100 cycles; accumulating straight into global memory cost a ~800-cycle round trip per
+// mark and dominated the short phases it measured) and flushes them into RolloutArgs::phase_cycles[wave][phase] at the end
+// of the launch (a profiling aid, off unless the caller passes a buffer)
 struct Prof {
-    long long* slot;  // &phase_cycles[wave * 16]
+    long long* slot;  // LDS: this wave's 16 accumulators
     long long t;
     bool on;
     __device__ __forceinline__ void mark(int phase) {
@@ -347,49 +351,96 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 
 // One linear op (+activation) for the workgroup's 16*R rows: in (LDS) -> out (LDS), both with row stride ld.
 // W / bias point at the packed fragments / padded biases of this op (pack_weights_kernel / pack_bias_kernel).
-template <int R, int ACT = -1>
+// CS >= 0: the number of column tiles is a compile-time fact (shape-specialised kernels): every wave's (CT, EX) follows
+// from it and the wave index through ONE branch, and only the two wave_gemm instances the shape needs are compiled;
+// CS < 0: it is read from the layer table and dispatched through the (full, nex) switches.
+template <int R, int ACT = -1, int CS = -1>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
                                           const int lane, Prof& prof) {
     const int KC = lm.Kp / kKChunk;
-    const int C = lm.Np / kTile;
-    const int full = C / kWaves, rem = C % kWaves;
-    // leftover units u = (column tile kWaves*full + u / R, row tile u % R), dealt round-robin to waves
-    const int nu = rem * R;
-    Extras ex;
-    ex.c0 = kWaves * full + wave / R;              ex.r0 = wave % R;
-    ex.c1 = kWaves * full + (wave + kWaves) / R;     ex.r1 = (wave + kWaves) % R;
-    ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; ex.r2 = (wave + 2 * kWaves) % R;
-    ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
-    const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;  // <= kMaxExtras since rem < kWaves, R <= 4
     // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
     // fragment registers must fit the 256 VGPRs two waves per SIMD leave each wave)
     constexpr int kMaxCT = kWaves >= 8 ? 2 : 3;
-    int done = 0;
-    while (full - done > kMaxCT) {
-        wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
-        done += kMaxCT;
-    }
-    const int c_first = wave + kWaves * done;
-    switch (full - done) {
-        case 0: wave_gemm_ex<R, 0, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-        case 1: wave_gemm_ex<R, 1, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-        case 2: wave_gemm_ex<R, 2, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-        default:
-            if constexpr (kMaxCT >= 3)
-                wave_gemm_ex<R, 3, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
-            break;
+    if constexpr (CS >= 0) {
+        constexpr int full = CS / kWaves, rem = CS % kWaves, nu = rem * R;
+        Extras ex;
+        ex.c0 = kWaves * full + wave / R;                ex.r0 = wave % R;
+        ex.c1 = kWaves * full + (wave + kWaves) / R;     ex.r1 = (wave + kWaves) % R;
+        ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; ex.r2 = (wave + 2 * kWaves) % R;
+        ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
+        constexpr int passes = full > kMaxCT ? (full - 1) / kMaxCT : 0;  // whole passes of kMaxCT tiles before the last one
+        constexpr int last = full - passes * kMaxCT;                      // 0 .. kMaxCT column tiles ride with the extras
+#pragma unroll
+        for (int p = 0; p < passes; ++p)
+            wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof);
+        const int c_first = wave + kWaves * kMaxCT * passes;
+        // the nu leftover units are dealt round-robin: waves below nu % kWaves hold one more than the others
+        constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
+        if constexpr (lo == hi) {
+            if constexpr (last > 0 || lo > 0) wave_gemm<R, last, lo, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+        } else {
+            if (wave < nu % kWaves) {
+                wave_gemm<R, last, hi, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+            } else {
+                if constexpr (last > 0 || lo > 0) wave_gemm<R, last, lo, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+            }
+        }
+    } else {
+        const int C = lm.Np / kTile;
+        const int full = C / kWaves, rem = C % kWaves;
+        // leftover units u = (column tile kWaves*full + u / R, row tile u % R), dealt round-robin to waves
+        const int nu = rem * R;
+        Extras ex;
+        ex.c0 = kWaves * full + wave / R;                ex.r0 = wave % R;
+        ex.c1 = kWaves * full + (wave + kWaves) / R;     ex.r1 = (wave + kWaves) % R;
+        ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; ex.r2 = (wave + 2 * kWaves) % R;
+        ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
+        const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;  // <= kMaxExtras since rem < kWaves, R <= 4
+        int done = 0;
+        while (full - done > kMaxCT) {
+            wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
+            done += kMaxCT;
+        }
+        const int c_first = wave + kWaves * done;
+        switch (full - done) {
+            case 0: wave_gemm_ex<R, 0, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            case 1: wave_gemm_ex<R, 1, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            case 2: wave_gemm_ex<R, 2, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            default:
+                if constexpr (kMaxCT >= 3)
+                    wave_gemm_ex<R, 3, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+                break;
+        }
     }
 }
 
+// Compile-time facts of a rollout-kernel instance; -1 = decided at run time.  Instances with HIDC >= 0 are the
+// SHAPE-SPECIALISED ("lean") kernels of the BASELINE configurations: hidden / output column-tile counts, normaliser kind,
+// obs preprocessing, reward and termination functions and the launch mode are template arguments, and everything those
+// shapes never use (expectation propagation, injected eps, traces, the phase profiler, batched / per-row initial states,
+// per-member logvar bounds) is compiled out.  The host picks an instance only when the model and the call match ALL of its
+// facts (launch.hpp select_*); anything else runs the generic instance.  Same arithmetic, instruction for instruction, in
+// the parts both execute: tests compare the two bit for bit.
+template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1>
+struct KSpec {
+    static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
+    static constexpr bool LEAN = HIDC_ >= 0;
+};
+
 // Layer l of the ensemble MLP with member `member`'s weights.
-template <int R, int ACT>
+template <int R, class S>
 __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
                                           const float* in, float* out, const int wave, const int lane, Prof& prof) {
     const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
     const float* W = md.w + (size_t)member * md.wmember + lm.woff;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
-    linear_op<R, ACT>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
+    if constexpr (S::LEAN) {
+        if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        else linear_op<R, S::ACT, S::OUTC>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
+    } else {
+        linear_op<R, S::ACT>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
+    }
 }
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
@@ -496,6 +547,7 @@ struct RolloutSmem {
     int* nodelta;    // [obs_dim]
     int* sched;      // [H] member slot of this workgroup per step (FAST)
     LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
+    long long* prof;   // [kWaves][16] phase-cycle accumulators (profiling aid)
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
@@ -513,6 +565,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += align16((size_t)obs_dim * 4);
     n += align16((size_t)horizon * 4);
     n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
+    n += align16((size_t)kWaves * 16 * 8);
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
@@ -536,10 +589,20 @@ __device__ __forceinline__ float softplus_fast(float x) {
 #endif
 template <int R> struct MinWaves { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
 
-// ACT = HIPETS_ACT_* : kernel specialised for that activation; ACT = -1: md.activation is read at run time.
-template <int R, int ACT>
+// S = KSpec<...>: the compile-time facts of this instance (generic: only the activation may be fixed; lean: the whole shape).
+template <int R, class S>
 __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
+    constexpr bool kLean = S::LEAN;
+    // facts that are template arguments in a lean instance and model / call fields in the generic one
+    const int normalizer = S::NORM >= 0 ? S::NORM : md.normalizer;
+    const int obs_process = S::OBSP >= 0 ? S::OBSP : md.obs_process;
+    const int reward_fn = S::REW >= 0 ? S::REW : md.reward_fn;
+    const int term_fn = S::TERM >= 0 ? S::TERM : md.term_fn;
+    const int lv_rows = kLean ? 1 : md.lv_rows;
+    const bool deterministic = kLean ? false : md.deterministic != 0;
+    float* const trace_next_obs = kLean ? nullptr : ra.trace_next_obs;
+    float* const trace_rewards = kLean ? nullptr : ra.trace_rewards;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RolloutSmem sm;
     {
@@ -559,13 +622,14 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
+        sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool fast = ra.mode == HIPETS_MODE_FAST;
-    const bool expectation = md.propagation == HIPETS_PROP_EXPECTATION;
+    const bool fast = S::KMODE >= 0 ? S::KMODE == HIPETS_MODE_FAST : ra.mode == HIPETS_MODE_FAST;
+    const bool expectation = kLean ? false : md.propagation == HIPETS_PROP_EXPECTATION;
     const int wg = blockIdx.x;
 
     // ---- which rollout rows does this workgroup own; per-dimension constants into LDS -------------
@@ -597,8 +661,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     }
     {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
         // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
-        const int nlv = md.deterministic ? 0 : md.lv_rows * md.out_dim;
-        const bool norm = md.normalizer != HIPETS_NORM_NONE;
+        const int nlv = deterministic ? 0 : lv_rows * md.out_dim;
+        const bool norm = normalizer != HIPETS_NORM_NONE;
         double c_nm = 0.0, c_ns = 1.0;
         float c_lo = 0.f, c_hi = 0.f;
         int c_nd = 0, c_lm = 0;
@@ -608,12 +672,12 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         if (tid < nlv) { c_lo = md.min_lv[tid]; c_hi = md.max_lv[tid]; }
         if (tid < md.obs_dim) c_nd = md.no_delta[tid];
         if (tid < n_meta) c_lm = reinterpret_cast<const int*>(md.layers)[tid];
-        if (norm && tid < md.in_dim) { sm.nmean[tid] = c_nm; sm.nstd[tid] = md.normalizer == HIPETS_NORM_F64 ? 1.0 / c_ns : c_ns; }  // f64: 1 / std, see build_input
+        if (norm && tid < md.in_dim) { sm.nmean[tid] = c_nm; sm.nstd[tid] = normalizer == HIPETS_NORM_F64 ? 1.0 / c_ns : c_ns; }  // f64: 1 / std, see build_input
         if (tid < nlv) { sm.minlv[tid] = c_lo; sm.maxlv[tid] = c_hi; }
         if (tid < md.obs_dim) sm.nodelta[tid] = c_nd;
         if (tid < n_meta) reinterpret_cast<int*>(sm.lmeta)[tid] = c_lm;
         if (norm)
-            for (int i = tid + kThreads; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = md.normalizer == HIPETS_NORM_F64 ? 1.0 / md.norm_std[i] : md.norm_std[i]; }
+            for (int i = tid + kThreads; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = normalizer == HIPETS_NORM_F64 ? 1.0 / md.norm_std[i] : md.norm_std[i]; }
         for (int i = tid + kThreads; i < nlv; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
         for (int i = tid + kThreads; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
     }
@@ -633,8 +697,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     const int s = i / md.obs_dim, d = i - s * md.obs_dim;
                     const int rid = sm.rowid[s];
                     if (fast) {
-                        if (ra.init_states) v[q] = rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f;
-                        else if (ra.pop_env > 0) v[q] = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
+                        if (!kLean && ra.init_states) v[q] = rid >= 0 ? ra.init_states[(size_t)rid * md.obs_dim + d] : 0.f;
+                        else if (!kLean && ra.pop_env > 0) v[q] = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
                         else v[q] = ra.s0[d];
                     } else if (rid >= 0) {
                         v[q] = ra.state[(size_t)rid * md.obs_dim + d];
@@ -658,11 +722,14 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     const int nblk = (md.out_dim + 3) / 4;
     const int Kp0 = md.Kp0;
     Prof prof;
-    prof.on = ra.phase_cycles != nullptr && wg == 0 && lane == 0;
-    prof.slot = ra.phase_cycles + wave * 16;
+    prof.on = !kLean && ra.phase_cycles != nullptr && wg == 0 && lane == 0;
+    prof.slot = sm.prof + wave * 16;
+    if (prof.on) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) prof.slot[i] = 0;
+        prof.slot[15] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11));  // where this wave landed (HW_REG_HW_ID: simd [5:4], cu [11:8])
+    }
     prof.t = prof.on ? clock64() : 0;
-    if (prof.on)  // slot 15: where this wave landed (HW_REG_HW_ID: simd [5:4], cu [11:8])
-        prof.slot[15] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11));
 
     // the step's actions (model_env.py:179-182: row r uses candidate r // P) come from HBM.  Each thread owns up to
     // kPrefetch (row, action-dim) elements; their addresses are fixed for the whole horizon up to the t * A term, and
@@ -722,7 +789,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 float x;
                 if (cc < md.obs_in) {
                     if constexpr (PLAIN) x = sm.state[s * md.obs_dim + cc];
-                    else x = processed_obs(sm.state + s * md.obs_dim, cc, md.obs_process);
+                    else x = processed_obs(sm.state + s * md.obs_dim, cc, obs_process);
                 } else {
                     x = actn_t[s * md.act_dim + (cc - md.obs_in)];
                 }
@@ -741,8 +808,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     auto build_input = [&](const int t) __attribute__((always_inline)) {
         using T = std::true_type;
         using F = std::false_type;
-        const bool plain = md.obs_process == HIPETS_OBS_NONE;
-        switch (md.normalizer) {
+        const bool plain = obs_process == HIPETS_OBS_NONE;
+        switch (normalizer) {
             case HIPETS_NORM_F64:
                 if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, T{});
                 else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, F{});
@@ -790,7 +857,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             float* nxt = sm.buf1;
             for (int l = 0; l < md.n_layers; ++l) {
                 prof.mark(12);
-                mlp_layer<R, ACT>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
@@ -801,9 +868,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 for (int i = tid; i < ROWS * md.out_total; i += kThreads) {
                     const int s = i / md.out_total, c = i % md.out_total;
                     float v = result[s * md.ld + c];
-                    if (!md.deterministic && c >= md.out_dim) {
+                    if (!deterministic && c >= md.out_dim) {
                         const int d = c - md.out_dim;
-                        const int bd = (md.lv_rows > 1 ? member * md.out_dim : 0) + d;
+                        const int bd = (lv_rows > 1 ? member * md.out_dim : 0) + d;
                         v = sm.maxlv[bd] - softplus_fast(sm.maxlv[bd] - v);
                         v = sm.minlv[bd] + softplus_fast(v - sm.minlv[bd]);
                     }
@@ -821,8 +888,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             constexpr bool EXPECT = decltype(expect_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
             const float inv_m = 1.0f / (float)md.M;
-            const float* lvmin = sm.minlv + (md.lv_rows > 1 ? member * md.out_dim : 0);  // this step's member owns the bounds
-            const float* lvmax = sm.maxlv + (md.lv_rows > 1 ? member * md.out_dim : 0);
+            const float* lvmin = sm.minlv + (lv_rows > 1 ? member * md.out_dim : 0);  // this step's member owns the bounds
+            const float* lvmax = sm.maxlv + (lv_rows > 1 ? member * md.out_dim : 0);
             for (int item = tid; item < ROWS * nblk; item += kThreads) {
                 const int s = item / nblk, blk = item % nblk;
                 const int rid = sm.rowid[s];
@@ -865,7 +932,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     if (d < md.obs_dim) {
                         const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
                         sm.state[s * md.obs_dim + d] = nobs;
-                        if (ra.trace_next_obs) ra.trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
+                        if (trace_next_obs) trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
                     } else if (d < md.out_dim) {
                         sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
                     }
@@ -875,7 +942,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         {
             using T = std::true_type;
             using F = std::false_type;
-            const int mode = md.deterministic ? 0 : (ra.eps != nullptr ? 1 : (ra.use_philox ? 2 : 0));
+            // lean instances: stochastic model, in-kernel Philox draws (the host selects them only then)
+            const int mode = kLean ? 2 : (deterministic ? 0 : (ra.eps != nullptr ? 1 : (ra.use_philox ? 2 : 0)));
             if (expectation) {
                 if (mode == 0) sample_impl(T{}, std::integral_constant<int, 0>{});
                 else if (mode == 1) sample_impl(T{}, std::integral_constant<int, 1>{});
@@ -897,9 +965,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             if (rid < 0) continue;
             const float* st = sm.state + s * md.obs_dim;
             const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
-            float r = reward_eval(st, ac, md.obs_dim, md.act_dim, md.reward_fn, sm.lrew[s]);
-            const bool done = term_eval(st, md.obs_dim, md.term_fn);
-            if (ra.trace_rewards) ra.trace_rewards[(size_t)t * ra.B + rid] = r;
+            float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
+            const bool done = term_eval(st, md.obs_dim, term_fn);
+            if (trace_rewards) trace_rewards[(size_t)t * ra.B + rid] = r;
             if (sm.term[s]) r = 0.f;
             sm.term[s] = sm.term[s] | (done ? 1 : 0);
             sm.tot[s] += r;
@@ -914,9 +982,13 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         const int rid = sm.rowid[s];
         if (rid < 0) continue;
         ra.totals[rid] = sm.tot[s];
-        if (!fast || ra.write_back) ra.term[rid] = (unsigned char)sm.term[s];
+        if (!fast || (!kLean && ra.write_back)) ra.term[rid] = (unsigned char)sm.term[s];
     }
-    if (!fast || ra.write_back) {
+    if (prof.on) {  // flush the phase accumulators of this wave
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ra.phase_cycles[wave * 16 + i] += prof.slot[i];
+    }
+    if (!fast || (!kLean && ra.write_back)) {
         for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
             const int s = i / md.obs_dim, d = i % md.obs_dim;
             const int rid = sm.rowid[s];

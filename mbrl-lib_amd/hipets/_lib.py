@@ -51,6 +51,7 @@ class RolloutOpts(C.Structure):
         ("no_sample", C.c_int32),
         ("rows_per_member", C.c_int32),
         ("n_env", C.c_int32),
+        ("generic_kernel", C.c_int32),
     ]
 
 
@@ -129,6 +130,7 @@ SYMBOLS = {
     "hipets_plan_cem_sharded": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_planet_set_model": (C.c_int, [_P, C.POINTER(PlanetDesc), _P]),
     "hipets_planet_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PlanetOpts), _P, _P]),
+    "hipets_plan_planet_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_timing_enable": (C.c_int, [_P, C.c_int32]),
     "hipets_timing_read": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int32]),
 }

@@ -141,7 +141,7 @@ class Engine:
                 trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
                 rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
                 phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1,
-                members: Optional[torch.Tensor] = None) -> torch.Tensor:
+                members: Optional[torch.Tensor] = None, generic_kernel: bool = False) -> torch.Tensor:
         """``members`` (EXACT mode): int64 [H, B] (random_model) or [B] (fixed_model) active-member slot of every row: the
         reference's ``torch.randint`` draws for BasicEnsemble models (basic_ensemble.py:122-129, 255-260), or any
         ``propagate_from_indices``-style assignment (util/math.py:180-196) for GaussianMLP models (no batch % members rule)."""
@@ -162,6 +162,7 @@ class Engine:
         B = pop * num_particles
         o = RolloutOpts()
         o.n_env = int(n_env)
+        o.generic_kernel = int(bool(generic_kernel))
         if mode not in _lib.MODES:
             raise ValueError("mode must be 'exact', 'fast' or 'device'")
         o.mode = _lib.MODES[mode]
@@ -585,6 +586,26 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self._lib.hipets_planet_rollout(self._h, _ptr(actions), _ptr(latent0), _ptr(belief0), pop, H, num_particles,
                                                        C.byref(o), _ptr(out), _stream(dev)))
+        return out
+
+    def plan_planet_cem(self, p: CemParams, x0, lower, upper, latent0: torch.Tensor, belief0: torch.Tensor, num_particles: int,
+                        seed: int = 0, plan_id: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Whole CEM plan over the PlaNet latent model on the device (hipets_plan_planet_cem)."""
+        spec = getattr(self, "planet_spec", None)
+        if spec is None:
+            raise HipetsError("Engine.planet_set_model() has not been called")
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        _check_dev(latent0, torch.float32, dev, "latent0", numel=spec.latent_size)
+        _check_dev(belief0, torch.float32, dev, "belief0", numel=spec.belief_size)
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_planet_cem(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper), _ptr(latent0), _ptr(belief0),
+                                                        num_particles, int(seed) & (2**64 - 1), int(plan_id) & (2**64 - 1), _ptr(out),
+                                                        _stream(dev)))
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------------

@@ -403,6 +403,28 @@ class PlaNetTrajectoryEvalFn:
             self.engine.planet_set_model(self.spec)
             self._version = planet_version(self._planet)
 
+    def prepare(self):
+        """What a call does before its rollout: re-pack changed weights, make them the engine's PlaNet model, fetch the live
+        model's saved posterior sample / belief.  Returns (latent0, belief0)."""
+        self.refresh()
+        if self.engine.planet_spec is not self.spec:
+            self.engine.planet_set_model(self.spec)
+        if self._planet is not None:  # planet.py:669-672
+            if self._planet._current_posterior_sample is None or self._planet._current_belief is None:
+                raise RuntimeError("PlaNetModel has no saved posterior: call update_posterior() before planning")
+            self.set_state(self._planet._current_posterior_sample, self._planet._current_belief)
+        if self._state is None:
+            raise RuntimeError("no latent state: call set_state(latent, belief) first")
+        return self._state
+
+    def evaluate_seeded(self, initial_state, action_sequences: torch.Tensor, seed: int, stream_id: int) -> torch.Tensor:
+        """One evaluation with explicit counter-based randomness (what iteration ``stream_id`` of the fused plan runs)."""
+        latent0, belief0 = self.prepare()
+        a = action_sequences
+        if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        return self.engine.planet_rollout(a, latent0, belief0, self.num_particles, seed=seed, stream_id=stream_id)
+
     def __call__(self, initial_state, action_sequences: torch.Tensor) -> torch.Tensor:
         self.refresh()
         if self.engine.planet_spec is not self.spec:
@@ -462,10 +484,15 @@ class _BoundObjective:
         return self.eval_fn(self.obs, action_sequences)
 
 
-def _fused_target(obj_fun) -> Optional[HipTrajectoryEvalFn]:
-    if isinstance(obj_fun, _BoundObjective) and isinstance(obj_fun.eval_fn, HipTrajectoryEvalFn):
-        if obj_fun.eval_fn.kernel_mode is not None:
-            return obj_fun.eval_fn
+def _fused_target(obj_fun, planet_ok: bool = False):
+    """The hipets objective behind ``obj_fun`` when it draws its randomness in-kernel (so that a whole optimisation can run
+    inside the library), else None.  ``planet_ok``: PlaNet latent objectives count too (CEM has a fused PlaNet plan)."""
+    if isinstance(obj_fun, _BoundObjective):
+        fn = obj_fun.eval_fn
+        if isinstance(fn, HipTrajectoryEvalFn) and fn.kernel_mode is not None:
+            return fn
+        if planet_ok and isinstance(fn, PlaNetTrajectoryEvalFn) and fn.mode == "fast":
+            return fn
     return None
 
 
@@ -572,12 +599,16 @@ class CEMOptimizer(Optimizer):
         # a hipets objective that draws its randomness in-kernel: iteration i of this call samples AND rolls out with the
         # counter-based streams (seed ^ objective seed, calls * iterations + i), whether the loop runs inside the library
         # (one hipets_plan_cem call) or here (callback / injected noise / force_generic): both give the same numbers
-        fused = _fused_target(obj_fun) if (x0.ndim == 2 and self.sampler == "philox") else None
+        fused = _fused_target(obj_fun, planet_ok=True) if (x0.ndim == 2 and self.sampler == "philox") else None
         if fused is not None and fused.engine is not self.engine:
             fused = None
         seed = (self.seed ^ fused.seed) if fused is not None else self.seed
         noise = kwargs.get("noise")  # optional injected z per iteration (parity tests)
         if fused is not None and callback is None and noise is None and not kwargs.get("force_generic", False):
+            if isinstance(fused, PlaNetTrajectoryEvalFn):  # the PlaNet latent planner: hipets_plan_planet_cem
+                latent0, belief0 = fused.prepare()
+                return self.engine.plan_planet_cem(self._params, x0, self.lower_bound, self.upper_bound, latent0, belief0,
+                                                   fused.num_particles, seed=seed, plan_id=self.calls)
             _prepare_fused(fused, [self.population_size])
             return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
                                         fused.num_particles, seed=seed, plan_id=self.calls)

@@ -66,6 +66,15 @@ def main():
         torch.cuda.synchronize()
         out["device"][f"R{R}"] = {"kernel_us_per_step": 1e3 * ms / n, "launches": n, "rollout_ms_kernels": ms / 5, "rollout_ms_wall_events_on_every_packet": e0.elapsed_time(e1) / 5,
                                   "rollout_ms_wall": f0.elapsed_time(f1) / 5}
+    for _ in range(3):
+        eng.rollout(actions, s0, P, mode="fast", seed=1, stream_id=1, generic_kernel=True)
+    eng.timing_enable(True)
+    eng.timing_read(reset=True)
+    for i in range(10):
+        eng.rollout(actions, s0, P, mode="fast", seed=1, stream_id=2 + i, generic_kernel=True)
+    n, ms = eng.timing_read(reset=True)
+    eng.timing_enable(False)
+    out["fast"]["R3_generic_kernel"] = {"ms": ms / n}
     pc = torch.zeros(8, 16, dtype=torch.int64, device=dev)
     eng.rollout(actions, s0, P, mode="fast", seed=1, stream_id=99, phase_cycles=pc)
     torch.cuda.synchronize()

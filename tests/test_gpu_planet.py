@@ -101,3 +101,72 @@ def test_planet_eval_fn_and_cem_agent(engine):
     eps = torch.randn(H, 16 * 8, 30, generator=g)
     r = pl.planet_rollout(pm, cands, latent0, belief0, 8, eps=eps)
     assert r[0] > r[1:].max(), r
+
+
+def test_fused_planet_cem_plan_equals_the_per_iteration_path_and_the_oracle(engine):
+    """hipets_plan_planet_cem (the PlaNet planner as one library call, clipped-normal CEM of planet_cheetah_run.yaml:29-35) is the
+    per-iteration CEMOptimizer loop bit for bit, and -- replayed with the plan's own exported draws, teacher-forced per
+    iteration -- the oracle's CEM over the oracle's PlaNet rollouts."""
+    from hipets.planning import _BoundObjective
+    from oracle import pets_oracle as po
+
+    L, A, Hb, F, H, pop, iters, P = 30, 6, 200, 200, 12, 1000, 10, 1  # conf sizes
+    pm = pl.make_synthetic_planet(L, A, Hb, F, seed=4)
+    fn = hipets.make_eval_fn(to_planet_spec(pm), P, engine=engine, seed=2)
+    g = torch.Generator().manual_seed(0)
+    latent0, belief0 = torch.randn(1, L, generator=g) * 0.3, torch.randn(1, Hb, generator=g) * 0.3
+    fn.set_state(latent0, belief0)
+    lower, upper = -torch.ones(H, A), torch.ones(H, A)
+    mk = lambda: hipets.CEMOptimizer(iters, 0.1, pop, lower.tolist(), upper.tolist(), 0.0, DEV, return_mean_elites=True,  # noqa: E731
+                                     clipped_normal=True, seed=1)
+    a, b = mk(), mk()
+    K = int(a.elite_num)
+    obj = _BoundObjective(fn, np.zeros((3, 64, 64), np.float32))
+    x0 = torch.zeros(H, A)
+    tr = engine.set_plan_trace(iters, pop, H, A, K)
+    fused = a.optimize(obj, x0=x0)
+    torch.cuda.synchronize()
+    engine.set_plan_trace(0)
+    generic = b.optimize(obj, x0=x0, callback=lambda *_: None)
+    assert torch.equal(fused, generic)
+    # replay: z of the clipped-normal sampler (mu 0, dispersion 1, wide bounds -> population == z), eps of the rollouts
+    seed, plan_id = a.seed ^ fn.seed, a.calls
+    p = engine.cem_params(pop, H, A, iters, K, 0.0, True, True)
+    one, zero = torch.ones(H, A, device=DEV), torch.zeros(H, A, device=DEV)
+    z = []
+    for i in range(iters):
+        buf = torch.empty(pop, H, A, device=DEV)
+        engine.cem_sample(p, zero, one, -1e3 * one, 1e3 * one, buf, seed=seed, stream_id=plan_id * iters + i)
+        z.append(buf.cpu())
+    it = {"i": 0}
+
+    def oracle_obj(population):
+        i = it["i"]
+        it["i"] += 1
+        # the rollout kernel's normals: planet rows use the PETS kernel's Philox streams with out_dim = latent size
+        eps = engine_normals(engine, H, pop * P, L, seed, plan_id * iters + i)
+        return pl.planet_rollout(pm, population, latent0, belief0, P, eps=eps)
+
+    teacher = [(tr["mus"][i].cpu(), tr["dispersions"][i].cpu()) for i in range(iters)]
+    rec = []
+    po.cem_optimize(oracle_obj, x0, lower, upper, iters, 0.1, pop, 0.0, return_mean_elites=True, clipped_normal=True, noise=z, record=rec,
+                    teacher=teacher)
+    for i in range(iters):
+        assert torch.allclose(tr["populations"][i].cpu(), rec[i]["population"], rtol=0, atol=1e-5), i
+        v, rv = tr["values"][i].cpu(), rec[i]["values"]
+        assert ((v - rv).abs() <= 1e-4 * torch.clamp(rv.abs(), min=1.0)).all(), i  # T2
+        if set(tr["elite_idx"][i].cpu().tolist()) == set(rec[i]["elite_idx"].tolist()):
+            assert torch.allclose(tr["mus"][i].cpu(), rec[i]["mu"], rtol=0, atol=1e-4), i  # T4
+            assert torch.allclose(tr["dispersions"][i].cpu(), rec[i]["disp"], rtol=1e-4, atol=1e-5), i
+    assert torch.equal(fused, tr["mus"][iters - 1])
+
+
+def engine_normals(engine, H, B, latent, seed, stream):
+    """eps [H, B, latent] a FAST PlaNet rollout draws for (seed, stream): the rollout kernels share rollout_normals4, so the PETS
+    export with a model whose out_dim equals the latent size returns them."""
+    from conftest import to_spec
+    from oracle import pets_oracle as po
+
+    om = po.make_synthetic_model(latent, 2, ensemble_size=1, hid=16, seed=0)
+    engine.set_model(to_spec(om, latent, 2))
+    return engine.fast_normals(H, B, seed, stream).cpu()

@@ -368,3 +368,18 @@ def test_gaussian_mlp_with_explicit_member_maps(engine, prop):
     nobs, rew, done = engine.step(x.to(DEV), a.to(DEV), mode="exact", sample=True, members=m1, eps=eps[0].to(DEV))
     r_nobs, r_rew, _ = po.step(om, x, a, member_of_row=m1, eps=eps[0], sample=True)
     assert torch.allclose(nobs.cpu(), r_nobs, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), r_rew, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[3], SIZES[4]], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}")
+def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case, mode):
+    """The BASELINE shapes (cfg2 / cfg1 / cfg4 / cfg5) run shape-specialised ("lean") instances of the rollout kernel -- layer
+    shapes, normaliser kind, reward / termination functions as template arguments, unused features compiled out.  Same
+    arithmetic: their returns equal the generic instance's bit for bit (opts.generic_kernel forces the latter)."""
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3)
+    b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=True)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all()
