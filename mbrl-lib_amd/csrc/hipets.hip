@@ -76,6 +76,10 @@ struct hipets_engine {
     DevBuf wpack, bpack, layer_meta, norm_mean, norm_std, min_lv, max_lv, no_delta, members;
     // rollout workspace
     DevBuf s0, state, totals, term, schedule, plan_schedule;
+    // DEVICE mode, persistent form: row exchange table, per-step permutation keys, timeout flag (host-mapped)
+    DevBuf exchange, step_keys;
+    int* error_flag = nullptr;
+    bool persistent_ok = true;
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
     // RCCL communicator (lazy-loaded librccl)
@@ -310,6 +314,11 @@ int hipets_create(int device, hipets_engine** out) {
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->lds_max = prop.sharedMemPerBlockOptin > 0 ? (size_t)prop.sharedMemPerBlockOptin : (size_t)prop.sharedMemPerBlock;
     if (e->lds_max > 160 * 1024) e->lds_max = 160 * 1024;
+    // timeout flag of the persistent DEVICE-mode kernel: host memory the device can write, read by the host without a sync
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->error_flag), sizeof(int), hipHostMallocMapped) != hipSuccess) e->error_flag = nullptr;
+    if (e->error_flag) *e->error_flag = 0;
+    const char* np = std::getenv("HIPETS_NO_PERSISTENT");
+    e->persistent_ok = e->error_flag != nullptr && !(np && np[0] == '1');
     *out = e;
     return 0;
 }
@@ -319,11 +328,12 @@ void hipets_destroy(hipets_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
     for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
-                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->mu, &e->disp, &e->population, &e->values,
+                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->mu, &e->disp, &e->population, &e->values,
                       &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (e->error_flag) (void)hipHostFree(e->error_flag);
     delete e;
 }
 
@@ -485,6 +495,12 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!actions || !o || !returns) return fail("null argument");
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
+    if (e->error_flag && *e->error_flag) {  // raised by an EARLIER launch: its returns were garbage
+        *e->error_flag = 0;
+        e->persistent_ok = false;  // fall back to one launch per step from now on
+        return fail("a persistent DEVICE-mode rollout timed out waiting for rows of another workgroup (its workgroups were not all "
+                    "resident); the results of that call are invalid.  Persistent launches are now disabled for this engine.");
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     const ModelDev& md = e->md;
@@ -567,7 +583,24 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
         // (state through HBM); TS-infinity / expectation rollouts of DEVICE mode keep their rows and run as ONE launch
         const bool per_step = !device || md.propagation == HIPETS_PROP_RANDOM_MODEL;
-        if (per_step) {
+        // DEVICE + random_model with every workgroup resident at once (one workgroup always fits a CU, so <= #CUs workgroups
+        // are): ONE launch for the horizon, rows handed over between workgroups through the tagged-granule table.  Larger
+        // batches (cfg4, cfg5: one step is >= 100 us of work) keep one launch per step.
+        const bool persistent = device && per_step && e->persistent_ok && domains * groups <= e->num_cu && H > 1;
+        if (persistent) {
+            const size_t nv = (size_t)md.obs_dim + 2;
+            if (e->exchange.ensure((size_t)B * nv * 8) || e->step_keys.ensure((size_t)H * sizeof(PermKeys))) return 1;
+            HCHECK(hipMemsetAsync(e->exchange.p, 0, (size_t)B * nv * 8, st));  // tag 0: no step's data
+            hipLaunchKernelGGL(step_keys_kernel, dim3((H + 63) / 64), dim3(64), 0, st, e->step_keys.as<PermKeys>(), H, (unsigned long long)o->seed,
+                               (unsigned long long)o->stream_id);
+            HCHECK(hipGetLastError());
+            ra.exchange = e->exchange.as<unsigned long long>();
+            ra.step_keys = e->step_keys.as<PermKeys>();
+            ra.error_flag = e->error_flag;
+            ra.t_begin = 0;
+            ra.t_end = H;
+            if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
+        } else if (per_step) {
             for (int t = 0; t < H; ++t) {
                 ra.t_begin = t;
                 ra.t_end = t + 1;

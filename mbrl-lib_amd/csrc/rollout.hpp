@@ -87,6 +87,13 @@ struct RolloutArgs {
     const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
     int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
     int generic_only;          // never pick a shape-specialised (lean) kernel instance (hipets_rollout_opts.generic_kernel)
+    // DEVICE mode, persistent form (all workgroups co-resident, ONE launch for the horizon): rows change workgroups every step
+    // through `exchange`, a [B][obs_dim + 2] table of 8-byte {value bits, step tag} granules (state dims, running total,
+    // terminated flag).  A granule is written by ONE write-through (sc1) 8-byte store and polled with sc1 loads until its
+    // tag is the awaited step: self-validating, so no fence, flag or grid barrier is involved (MI355X_MICROARCH.md R2).
+    unsigned long long* exchange;  // null: per-step launches
+    const PermKeys* step_keys;     // DEVICE [H]: round keys of every step's permutation
+    int* error_flag;               // set to 1 when a poll exceeds its spin bound (another workgroup was not resident)
 };
 
 // D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
@@ -649,16 +656,18 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // unbalanced member maps (BasicEnsemble) pad every member's slots with -1 at the tail: nothing to do here
         if (perm && perm[(long long)domain * ra.rows_per_domain + j0] < 0) return;
         // DEVICE mode: the step's permutation is a keyed bijection evaluated on the fly (common.hpp perm_apply)
+        const PermKeys keys0 = ra.exchange ? ra.step_keys[ra.t_begin] : ra.perm_keys;
         for (int s = tid; s < ROWS; s += kThreads) {
             const int j = j0 + s;
             int rid = -1;
             if (j < ra.rows_per_domain) {
                 const int jj = domain * ra.rows_per_domain + j;
-                rid = perm ? (int)perm[jj] : (ra.perm_n ? (int)perm_apply((unsigned)jj, ra.perm_n, ra.perm_a, ra.perm_b, ra.perm_keys) : jj);
+                rid = perm ? (int)perm[jj] : (ra.perm_n ? (int)perm_apply((unsigned)jj, ra.perm_n, ra.perm_a, ra.perm_b, keys0) : jj);
             }
             sm.rowid[s] = rid;
         }
     }
+    const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
     {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
         // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
         const int nlv = deterministic ? 0 : lv_rows * md.out_dim;
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                         else if (!kLean && ra.pop_env > 0) v[q] = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
                         else v[q] = ra.s0[d];
                     } else if (rid >= 0) {
-                        v[q] = ra.state[(size_t)rid * md.obs_dim + d];
+                        v[q] = persist ? ra.s0[d] : ra.state[(size_t)rid * md.obs_dim + d];  // persistent form starts from the tiled s0 itself
                     }
                 }
             }
@@ -713,8 +722,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
         for (int s = tid; s < ROWS; s += kThreads) {
             const int rid = sm.rowid[s];
-            sm.tot[s] = (!fast && rid >= 0) ? ra.totals[rid] : 0.f;
-            sm.term[s] = (!fast && rid >= 0) ? (int)ra.term[rid] : 0;
+            sm.tot[s] = (!fast && !persist && rid >= 0) ? ra.totals[rid] : 0.f;
+            sm.term[s] = (!fast && !persist && rid >= 0) ? (int)ra.term[rid] : 0;
             sm.lrew[s] = 0.f;
         }
     };
@@ -737,16 +746,19 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     constexpr int kPrefetch = 4;
     const int n_act = ROWS * md.act_dim;
     long long act_base[kPrefetch];  // element offset of (candidate, t = 0, a); -1 = nothing to fetch
+    auto compute_act_base = [&]() __attribute__((always_inline)) {  // from sm.rowid (again whenever the workgroup's rows change)
 #pragma unroll
-    for (int q = 0; q < kPrefetch; ++q) {
-        const int i = tid + q * kThreads;
-        act_base[q] = -1;
-        if (i < n_act) {
-            const int s = i / md.act_dim, a = i % md.act_dim;
-            const int rid = sm.rowid[s];
-            if (rid >= 0) act_base[q] = (long long)(rid / ra.P) * ra.H * md.act_dim + a;
+        for (int q = 0; q < kPrefetch; ++q) {
+            const int i = tid + q * kThreads;
+            act_base[q] = -1;
+            if (i < n_act) {
+                const int s = i / md.act_dim, a = i % md.act_dim;
+                const int rid = sm.rowid[s];
+                if (rid >= 0) act_base[q] = (long long)(rid / ra.P) * ra.H * md.act_dim + a;
+            }
         }
-    }
+    };
+    compute_act_base();
     auto fetch_actions_rest = [&](const int t) __attribute__((always_inline)) {  // elements beyond kPrefetch per thread (very wide action spaces)
         float* actn_t = sm.actn + (t & 1) * n_act;
         for (int i = tid + kPrefetch * kThreads; i < n_act; i += kThreads) {
@@ -840,7 +852,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     for (int t = ra.t_begin; t < ra.t_end; ++t) {
         const bool more = t + 1 < ra.t_end;
         float av[kPrefetch];
-        if (more) fetch_actions_issue(t + 1, av);  // consumed after the sampling phase: the HBM / L2 latency hides behind the MLP
+        if (more && !persist) fetch_actions_issue(t + 1, av);  // consumed after the sampling phase: the HBM / L2 latency hides behind the MLP
         const int n_run = expectation ? md.M : 1;
         float* result = nullptr;
         int member = 0;
@@ -954,7 +966,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 else sample_impl(F{}, std::integral_constant<int, 2>{});
             }
         }
-        if (more) fetch_actions_commit(t + 1, av);
+        if (more && !persist) fetch_actions_commit(t + 1, av);
         __syncthreads();
         prof.mark(9);
 
@@ -972,9 +984,85 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             sm.term[s] = sm.term[s] | (done ? 1 : 0);
             sm.tot[s] += r;
         }
-        if (more) build_input(t + 1);
+        if (more && !persist) build_input(t + 1);
         __syncthreads();
         prof.mark(10);
+
+        if (more && persist) {
+            // ---- hand the rows over: publish what this workgroup computed, become the owner of other rows, collect them ----
+            const int NV = md.obs_dim + 2;  // state dims, running total, terminated flag
+            const unsigned long long tag = (unsigned long long)(t + 1) << 32;
+            for (int i = tid; i < ROWS * NV; i += kThreads) {
+                const int s = i / NV, v = i - s * NV;
+                const int rid = sm.rowid[s];
+                if (rid < 0) continue;
+                const unsigned bits = v < md.obs_dim ? __float_as_uint(sm.state[s * md.obs_dim + v])
+                                                     : (v == md.obs_dim ? __float_as_uint(sm.tot[s]) : (unsigned)sm.term[s]);
+                __hip_atomic_store(ra.exchange + (size_t)rid * NV + v, tag | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1, 8 B
+            }
+            __syncthreads();  // everyone has read rowid / state / tot / term of the old rows
+            {
+                const int j0 = (wg % ra.groups) * ROWS;
+                const PermKeys keys = ra.step_keys[t + 1];
+                for (int s = tid; s < ROWS; s += kThreads) {
+                    const int j = j0 + s;
+                    sm.rowid[s] = j < ra.rows_per_domain
+                                      ? (int)perm_apply((unsigned)(domain * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, keys) : -1;
+                }
+            }
+            __syncthreads();
+            compute_act_base();
+            float av2[kPrefetch];
+            fetch_actions_issue(t + 1, av2);  // in flight while the rows arrive
+            constexpr int kG = 4;            // granules in flight per thread and round
+            for (int base = tid; base < ROWS * NV; base += kG * kThreads) {
+                const unsigned long long* src[kG];
+                unsigned long long g[kG];
+#pragma unroll
+                for (int q = 0; q < kG; ++q) {
+                    const int i = base + q * kThreads;
+                    src[q] = nullptr;
+                    g[q] = tag;  // rows of the padding: zero state, total, flag
+                    if (i < ROWS * NV) {
+                        const int s = i / NV, v = i - s * NV;
+                        const int rid = sm.rowid[s];
+                        if (rid >= 0) src[q] = ra.exchange + (size_t)rid * NV + v;
+                    }
+                }
+                for (int spins = 0;; ++spins) {
+                    bool ready = true;
+#pragma unroll
+                    for (int q = 0; q < kG; ++q)
+                        if (src[q]) {
+                            g[q] = __hip_atomic_load(src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1 line
+                            if ((g[q] >> 32) == (unsigned long long)(t + 1)) src[q] = nullptr;
+                            else ready = false;
+                        }
+                    if (ready) break;
+                    if (spins > (1 << 21)) {  // ~ seconds: the producer is not running (grid not co-resident) -- give up loudly
+                        *ra.error_flag = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int q = 0; q < kG; ++q) {
+                    const int i = base + q * kThreads;
+                    if (i < ROWS * NV) {
+                        const int s = i / NV, v = i - s * NV;
+                        const unsigned bits = (unsigned)g[q];
+                        if (v < md.obs_dim) sm.state[s * md.obs_dim + v] = __uint_as_float(bits);
+                        else if (v == md.obs_dim) sm.tot[s] = __uint_as_float(bits);
+                        else sm.term[s] = (int)bits;
+                    }
+                }
+            }
+            for (int s = tid; s < ROWS; s += kThreads) sm.lrew[s] = 0.f;
+            fetch_actions_commit(t + 1, av2);
+            __syncthreads();
+            build_input(t + 1);
+            __syncthreads();
+        }
     }
 
     // ---- write back -------------------------------------------------------------------------------
@@ -982,13 +1070,13 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         const int rid = sm.rowid[s];
         if (rid < 0) continue;
         ra.totals[rid] = sm.tot[s];
-        if (!fast || (!kLean && ra.write_back)) ra.term[rid] = (unsigned char)sm.term[s];
+        if ((!fast && !persist) || (!kLean && ra.write_back)) ra.term[rid] = (unsigned char)sm.term[s];
     }
     if (prof.on) {  // flush the phase accumulators of this wave
 #pragma unroll
         for (int i = 0; i < 16; ++i) ra.phase_cycles[wave * 16 + i] += prof.slot[i];
     }
-    if (!fast || (!kLean && ra.write_back)) {
+    if ((!fast && !persist) || (!kLean && ra.write_back)) {
         for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
             const int s = i / md.obs_dim, d = i % md.obs_dim;
             const int rid = sm.rowid[s];

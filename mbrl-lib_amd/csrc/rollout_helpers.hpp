@@ -84,6 +84,12 @@ __global__ void export_perms_kernel(long long* out, int H, unsigned n, unsigned 
     out[i] = (long long)perm_apply(j, n, a, b, perm_round_keys(perm_key(seed, stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t)));
 }
 
+// round keys of the H per-step permutations of a DEVICE-mode rollout (persistent form reads them from memory)
+__global__ void step_keys_kernel(PermKeys* keys, int H, unsigned long long seed, unsigned long long stream_id) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < H) keys[t] = perm_round_keys(perm_key(seed, stream_id, (unsigned)t));
+}
+
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
 //   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
 // so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
