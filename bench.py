@@ -12,7 +12,8 @@ weights (reference initialiser), fp32 arithmetic end to end (fp64 input normalis
 
 --mode (randomness of the rollouts inside the fused plan):
   device  the reference's propagation semantics: ONE balanced permutation of all 10 000 rows per step, iid eps, drawn
-          in-kernel; one rollout-kernel launch per step (rows change workgroups every step).  THE HEADLINE.
+          in-kernel; rows change workgroups every step -- through HBM inside one persistent launch per rollout when all
+          workgroups are co-resident (cfg2: 210 <= 256 CUs), else one launch per step.  THE HEADLINE.
   fast    one launch per rollout, block-balanced member schedule (reported as the `fast_mode` block of the same line).
 
 N>1 (BASELINE.json configs[2]): the SAME pop-500 plan with its candidates sharded over N ranks (one process per GPU,
@@ -261,12 +262,20 @@ def main():
         else:
             objective = _BoundObjective(eval_fn, s0)  # fused hipets_plan_cem
             plan = lambda: opt.optimize(objective, x0=x0)  # noqa: E731
-        for _ in range(warmup):
+        for _ in range(max(0, warmup - 1)):
             plan()
-        # hipEvents ride on the dispatch packets of the rollout kernel INSIDE the timed region.  DEVICE mode launches one short
-        # kernel per step back to back (150 per plan): a completion signal on every packet costs ~4.6 us each there (measured:
-        # 7.83 vs 7.14 ms per plan), so every 8th launch is sampled; FAST mode's 5 launches per plan are all timed.
-        engine.timing_enable(8 if mode == "device" else 1)
+        # the last warm-up plan counts the rollout-kernel launches of a plan: FAST mode and the persistent form of DEVICE mode
+        # launch once per rollout (the whole horizon), per-step DEVICE mode once per step
+        engine.timing_enable(1)
+        engine.timing_read(reset=True)
+        plan()
+        torch.cuda.synchronize()
+        per_plan, _ = engine.timing_read(reset=True)
+        # hipEvents ride on the dispatch packets of the rollout kernel INSIDE the timed region.  Back-to-back short launches
+        # (150 per plan in per-step DEVICE mode) pay ~4.6 us per packet that carries a completion signal (measured: 7.83 vs
+        # 7.14 ms per plan), so there every 8th launch is sampled; otherwise every launch is timed.
+        stride = 8 if per_plan > 4 * ITERS else 1
+        engine.timing_enable(stride)
         engine.timing_read(reset=True)
         barrier()
         t0 = time.perf_counter()
@@ -281,14 +290,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         assert torch.isfinite(sol).all()
-        return el, launches_, kernel_ms_
+        return el, launches_, kernel_ms_, max(1, round(ITERS * HORIZON / max(per_plan, 1))), stride
 
-    def roofline_block(mode, pop_total, launches, kernel_ms):
-        """Dominant kernel = hipets::rollout_kernel.  DEVICE mode: one launch = ONE step of the local rows; FAST mode: one
-        launch = the whole horizon.  achieved = algorithmic FLOP of a launch / its average duration (hipEvents riding on
-        every dispatch packet of the timed region, on the launch stream)."""
+    def roofline_block(mode, pop_total, launches, kernel_ms, steps_per_launch, stride):
+        """Dominant kernel = hipets::rollout_kernel.  One launch covers `steps_per_launch` steps of the local rows: the whole
+        horizon in FAST mode and in DEVICE mode's persistent form, ONE step when DEVICE mode launches per step (batches too
+        large to be co-resident).  achieved = algorithmic FLOP of a launch / its average duration (hipEvents riding on the
+        dispatch packets of the timed region, on the launch stream)."""
         local_pop = -(-pop_total // world) if (world > 1 and sharded != "fallback") else pop_total  # largest shard
-        steps_per_launch = 1 if mode == "device" else HORIZON
         alg = flops_cs * local_pop * PARTICLES * steps_per_launch
         avg_s = (kernel_ms / max(launches, 1)) * 1e-3
         ach = alg / avg_s / 1e12 if launches else None
@@ -303,24 +312,24 @@ def main():
                 "traffic": traffic, "kernel": "hipets::rollout_kernel", "launches": launches, "avg_launch_ms": 1e3 * avg_s if launches else None,
                 "algorithmic_flops_per_launch": alg, "flops_per_candidate_step": flops_cs,
                 "launch_covers": f"{local_pop} candidates x {PARTICLES} particles x {steps_per_launch} step(s)",
-                "launches_timed": f"every {8 if mode == 'device' else 1}-th launch of the timed region"}
+                "launches_timed": "every launch of the timed region" if stride == 1 else f"every {stride}-th launch of the timed region"}
 
     # N = 1: BASELINE.json configs[1].  N > 1: configs[2] = the SAME pop-500 plan sharded ("strong"); --scaling weak keeps pop 500 / rank
     pop = POP * world if (world > 1 and args.scaling == "weak") else POP
-    elapsed, launches, kernel_ms = run(args.mode, pop, args.steps, args.warmup)
-    roof = roofline_block(args.mode, pop, launches, kernel_ms)
+    elapsed, launches, kernel_ms, spl, stride = run(args.mode, pop, args.steps, args.warmup)
+    roof = roofline_block(args.mode, pop, launches, kernel_ms, spl, stride)
     extras = {}
     other = "fast" if args.mode == "device" else "device"
     if not args.no_extras:
         n_other = max(3, args.steps // 3)
-        e2, l2, k2 = run(other, pop, n_other, 2)
-        r2 = roofline_block(other, pop, l2, k2)
+        e2, l2, k2, spl2, stride2 = run(other, pop, n_other, 2)
+        r2 = roofline_block(other, pop, l2, k2, spl2, stride2)
         extras[f"{other}_mode"] = {"workload": f"the same plan with mode='{other}' rollouts", "value": n_other * ITERS * pop * PARTICLES * HORIZON / e2,
                                    "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e2 / n_other, "roofline": r2}
     if world > 1 and not args.no_extras:
         alt_pop = POP if args.scaling == "weak" else POP * world
         n_alt = max(3, args.steps // 3)
-        e3, _, _ = run(args.mode, alt_pop, n_alt, 2)
+        e3 = run(args.mode, alt_pop, n_alt, 2)[0]
         extras["weak_scaling" if args.scaling == "strong" else "cfg3_strong"] = {
             "workload": f"pop {alt_pop} in total ({alt_pop // world} per rank) sharded over {world} ranks", "value": n_alt * ITERS * alt_pop * PARTICLES * HORIZON / e3,
             "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e3 / n_alt}
@@ -380,7 +389,8 @@ def main():
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     plans_done = args.steps * (world if sharded == "fallback" else 1)  # fallback: every rank planned on its own
     value = plans_done * cand_steps_per_plan / elapsed
-    mode_text = {"device": "DEVICE (reference TS1 semantics: one balanced permutation of all rows per step + iid eps, drawn in-kernel; one launch per step)",
+    mode_text = {"device": "DEVICE (reference TS1 semantics: one balanced permutation of all rows per step + iid eps, drawn in-kernel; "
+                           + ("one persistent launch per rollout, rows handed over between workgroups through HBM)" if spl > 1 else "one launch per step)"),
                  "fast": "FAST (in-kernel Philox, block-balanced TS1, one launch per rollout)"}[args.mode]
     if world == 1:
         workload = ("BASELINE.json configs[1]: PETS HalfCheetah obs=17 act=6, GaussianMLP ensemble=5 (4x200 SiLU, TS1), "

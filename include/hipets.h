@@ -180,6 +180,13 @@ int hipets_fast_normals(hipets_engine* e, int32_t horizon, int32_t batch, uint64
 int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id, int64_t* perms,
                         void* stream);
 
+/* DEVICE-mode rollouts with a fresh permutation per step (random_model) run as ONE persistent launch when all their
+ * workgroups are co-resident (<= one per CU): rows change workgroups every step through a table of 8-byte {value, step tag}
+ * granules in HBM (write-through stores, polled loads; no grid barrier).  Larger batches launch once per step.  Every poll is
+ * bounded: if a producer never shows up the kernel raises a host-visible flag, the NEXT call on the engine fails with that
+ * report and the engine falls back to per-step launches.  on = 0 forces per-step launches (also: env HIPETS_NO_PERSISTENT=1). */
+int hipets_set_persistent(hipets_engine* e, int32_t on);
+
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {
     int32_t population_size;

@@ -792,6 +792,13 @@ int hipets_set_plan_mode(hipets_engine* e, int32_t mode) {
     return 0;
 }
 
+int hipets_set_persistent(hipets_engine* e, int32_t on) {
+    if (!e) return fail("null engine");
+    if (on && !e->error_flag) return fail("persistent DEVICE-mode launches need the host-mapped timeout flag, which could not be allocated");
+    e->persistent_ok = on != 0;
+    return 0;
+}
+
 int hipets_set_plan_trace(hipets_engine* e, const hipets_plan_trace* t) {
     if (!e) return fail("null engine");
     e->has_trace = t != nullptr;

@@ -117,3 +117,19 @@ def test_device_mode_rejects_basic_ensemble_member_maps(engine):
     a = torch.zeros(4, 3, 6, device=DEV)
     with pytest.raises(hipets.HipetsError, match="BasicEnsemble"):
         engine.rollout(a, np.zeros(17, np.float32), 2, mode="device")
+
+
+@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6]], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_persistent_and_per_step_launches_agree_bitwise(engine, case):
+    """DEVICE-mode rollouts whose workgroups are all co-resident run as ONE launch with the rows handed over between workgroups
+    through tagged granules; forbidding that (one launch per step, state through HBM between kernels) must not change a bit."""
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    a = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=77, stream_id=9)
+    engine.set_persistent(False)
+    try:
+        b = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=77, stream_id=9)
+    finally:
+        engine.set_persistent(True)
+    assert torch.equal(a, b)
