@@ -143,13 +143,53 @@ struct GemmFrags {
     f32x4 ax[EX > 0 ? EX : 1];
 };
 
+// Cross-layer prefetch (shape-specialised kernels): a wave's chunk-0 weight fragments and biases of the NEXT linear op are
+// requested from L2 right after the current op's k loop, so that their ~800-cycle latency passes behind the epilogue
+// (activation, LDS stores), the layer barrier and the next op's address set-up instead of stalling the first MFMA.
+constexpr int kPreCT = 3;  // >= the column tiles a wave carries through one wave_gemm (kMaxCT in linear_op)
+struct Pre {
+    f32x4 b[kPreCT], bx[kMaxExtras];    // chunk-0 weight fragments of the strided / extra units
+    f32x4 bv[kPreCT], bvx[kMaxExtras];  // their biases
+};
+struct NextOp {  // this wave's share of the op to prefetch for (wave-uniform)
+    const float* W;
+    const float* bias;
+    int KC, c_first, ct, ex_n;  // ct strided column tiles from c_first, ex_n extra units
+    int tail_steps;             // LayerMeta::tail_steps of the op
+    Extras ex;
+    bool valid;
+};
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for global loads in flight
+// (__syncthreads() also drains vmcnt, which would expose the latency of the prefetched weight fragments at every barrier)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void prefetch_issue(const NextOp& n, const int lane, Pre& pre) {
+    if (!n.valid) return;
+    const char* Wb = reinterpret_cast<const char*>(n.W);
+    const int exc[kMaxExtras] = {n.ex.c0, n.ex.c1, n.ex.c2, n.ex.c3};
+#pragma unroll
+    for (int ct = 0; ct < kPreCT; ++ct)
+        if (ct < n.ct) {
+            pre.b[ct] = *reinterpret_cast<const f32x4*>(Wb + (size_t)(unsigned)(((n.c_first + kWaves * ct) * n.KC * 64 + lane) * 16));
+            pre.bv[ct] = *reinterpret_cast<const f32x4*>(n.bias + (n.c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
+        }
+#pragma unroll
+    for (int e = 0; e < kMaxExtras; ++e)
+        if (e < n.ex_n) {
+            pre.bx[e] = *reinterpret_cast<const f32x4*>(Wb + (size_t)(unsigned)((exc[e] * n.KC * 64 + lane) * 16));
+            pre.bvx[e] = *reinterpret_cast<const f32x4*>(n.bias + exc[e] * 16 + 4 * (lane >> 4));
+        }
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests HERE (the scheduler would sink them to their first use)
+}
+
 // ACT >= 0: the activation is a compile-time fact (one epilogue in the code); ACT < 0: `act` selects it at run time.
-template <int R, int CT, int EX, int ACT>
+// PRE: chunk 0's weight fragments and the biases are already in `pre` (prefetch_issue by the previous op); after the k loop
+// the next op's are requested into `pre` again (`nxt`).
+template <int R, int CT, int EX, int ACT, bool PRE = false>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC,
                                           const int tail_steps, const int c_first, const Extras ex,
                                           const bool apply_act, const int act, const float slope, const int lane,
-                                          Prof& prof) {
+                                          Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr) {
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
     f32x4 acc[CTn][R];
@@ -173,10 +213,17 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     const float* ap = in + (lane & 15) * ld + 4 * (lane >> 4);
     // biases of this lane's columns: loaded before the k loop so their latency hides behind it
     f32x4 bv[CTn], bvx[EXn];
+    if constexpr (PRE) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + (c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
+        for (int ct = 0; ct < CT; ++ct) bv[ct] = pre->bv[ct];
 #pragma unroll
-    for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
+        for (int e = 0; e < EX; ++e) bvx[e] = pre->bvx[e];
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + (c_first + kWaves * ct) * 16 + 4 * (lane >> 4));
+#pragma unroll
+        for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
+    }
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
         const char* Wk = Wb + (size_t)kk * 1024;
 #pragma unroll
@@ -241,7 +288,18 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // sched_barrier(0) pins "issue the next chunk's loads, THEN this chunk's MFMAs": without it the machine
     // scheduler sinks each load group down to its first use and the pipeline degenerates to load->wait->compute.
     GemmFrags<R, CT, EX> f0, f1;
-    load(f0, 0);
+    if constexpr (PRE) {  // chunk 0: weights are in registers already, only the activation fragments come from LDS
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) f0.b[ct] = pre->b[ct];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) f0.bx[e] = pre->bx[e];
+#pragma unroll
+        for (int r = 0; r < R; ++r) f0.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) f0.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e]);
+    } else {
+        load(f0, 0);
+    }
     // accumulators start at the bias (C input of the first MFMA) instead of zero: no add in the epilogue.  Initialised AFTER
     // chunk 0's fragment loads were issued: the bias loads are older, so waiting for them leaves the fragments in flight
     // (initialising first serialised two L2 round trips per layer: ~1.2k cycles of "set-up" per layer in the phase profile)
@@ -283,6 +341,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     mfma_drain();
     __builtin_amdgcn_sched_barrier(0);
     prof.mark(11);
+    if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
 
     // epilogue: D[row = 4*(lane>>4)+i][col = lane&15] -> bias, activation, next layer's A image.
     // The activation switch is hoisted OUT of the element loops: one compact straight-line body per
@@ -361,10 +420,10 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 // CS >= 0: the number of column tiles is a compile-time fact (shape-specialised kernels): every wave's (CT, EX) follows
 // from it and the wave index through ONE branch, and only the two wave_gemm instances the shape needs are compiled;
 // CS < 0: it is read from the layer table and dispatched through the (full, nex) switches.
-template <int R, int ACT = -1, int CS = -1>
+template <int R, int ACT = -1, int CS = -1, bool PRE = false>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
-                                          const int lane, Prof& prof) {
+                                          const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr) {
     const int KC = lm.Kp / kKChunk;
     // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
     // fragment registers must fit the 256 VGPRs two waves per SIMD leave each wave)
@@ -384,13 +443,18 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         const int c_first = wave + kWaves * kMaxCT * passes;
         // the nu leftover units are dealt round-robin: waves below nu % kWaves hold one more than the others
         constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
+        static_assert(!PRE || passes == 0, "cross-layer prefetch needs the op to fit one wave_gemm per wave");
         if constexpr (lo == hi) {
-            if constexpr (last > 0 || lo > 0) wave_gemm<R, last, lo, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+            if constexpr (last > 0 || lo > 0)
+                wave_gemm<R, last, lo, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
+            else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);  // nothing to compute here: still fetch for the next op
         } else {
             if (wave < nu % kWaves) {
-                wave_gemm<R, last, hi, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+                wave_gemm<R, last, hi, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
             } else {
-                if constexpr (last > 0 || lo > 0) wave_gemm<R, last, lo, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+                if constexpr (last > 0 || lo > 0)
+                    wave_gemm<R, last, lo, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
+                else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
             }
         }
     } else {
@@ -434,6 +498,47 @@ struct KSpec {
     static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
     static constexpr bool LEAN = HIDC_ >= 0;
 };
+
+// can an op with CS column tiles take part in the cross-layer prefetch? (one wave_gemm per wave, see linear_op)
+template <int CS> struct PreOk { static constexpr bool value = CS >= 0 && CS / kWaves <= (kWaves >= 8 ? 2 : 3); };
+
+// this wave's share of an op with CS column tiles (the (CT, EX, c_first, extras) linear_op<.., CS> derives), for prefetch_issue
+template <int R, int CS>
+__device__ __forceinline__ NextOp describe_op(const float* W, const float* bias, const int KC, const int tail_steps, const int wave) {
+    constexpr int full = CS / kWaves, rem = CS % kWaves, nu = rem * R;
+    constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
+    NextOp n;
+    n.W = W; n.bias = bias; n.KC = KC; n.c_first = wave; n.ct = full; n.tail_steps = tail_steps;
+    n.ex_n = lo == hi ? lo : (wave < nu % kWaves ? hi : lo);
+    n.ex.c0 = kWaves * full + wave / R;                n.ex.r0 = wave % R;
+    n.ex.c1 = kWaves * full + (wave + kWaves) / R;     n.ex.r1 = (wave + kWaves) % R;
+    n.ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; n.ex.r2 = (wave + 2 * kWaves) % R;
+    n.ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; n.ex.r3 = (wave + 3 * kWaves) % R;
+    n.valid = true;
+    return n;
+}
+
+// the op `l` of member `member` as a prefetch target (lean kernels: hidden ops have S::HIDC column tiles, the last S::OUTC)
+template <int R, class S>
+__device__ __forceinline__ NextOp describe_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member, const int wave) {
+    const LayerMeta lm = lmeta[l];
+    const float* W = md.w + (size_t)member * md.wmember + lm.woff;
+    const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
+    if (l < md.n_layers - 1) return describe_op<R, S::HIDC>(W, bias, lm.Kp / kKChunk, lm.tail_steps, wave);
+    return describe_op<R, S::OUTC>(W, bias, lm.Kp / kKChunk, lm.tail_steps, wave);
+}
+
+// An op with the cross-layer prefetch: runs from the descriptor `cur` that was computed (and prefetched for) one op earlier --
+// every op's pointers and shares are derived exactly once --, consumes `pre`, refills it for `nxt`
+template <int R, class S>
+__device__ __forceinline__ void mlp_layer_pre(const ModelDev& md, const bool last_op, const NextOp& cur, const float* in, float* out,
+                                              const int wave, const int lane, Prof& prof, Pre& pre, const NextOp& nxt) {
+    LayerMeta lm;
+    lm.Kp = cur.KC * kKChunk;
+    lm.tail_steps = cur.tail_steps;
+    if (!last_op) linear_op<R, S::ACT, S::HIDC, true>(cur.W, cur.bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, &pre, &nxt);
+    else linear_op<R, S::ACT, S::OUTC, true>(cur.W, cur.bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof, &pre, &nxt);
+}
 
 // Layer l of the ensemble MLP with member `member`'s weights.
 template <int R, class S>
@@ -601,6 +706,13 @@ template <int R, class S>
 __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
     constexpr bool kLean = S::LEAN;
+    // cross-layer weight prefetch (wave_gemm PRE): measured on MI355X and left OFF -- cfg2 FAST 1.054 ms with it (1.073 before
+    // the descriptors were derived only once and the layer barriers stopped draining vmcnt) against 1.021 ms without: the
+    // ~800-cycle first-fragment latency it hides is outweighed by 56 more live VGPRs and the extra scalar work between layers
+#ifndef HIPETS_CROSS_LAYER_PREFETCH
+#define HIPETS_CROSS_LAYER_PREFETCH 0
+#endif
+    constexpr bool kPre = HIPETS_CROSS_LAYER_PREFETCH && kLean && PreOk<S::HIDC>::value && PreOk<S::OUTC>::value;
     // facts that are template arguments in a lean instance and model / call fields in the generic one
     const int normalizer = S::NORM >= 0 ? S::NORM : md.normalizer;
     const int obs_process = S::OBSP >= 0 ? S::OBSP : md.obs_process;
@@ -668,6 +780,16 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     }
     const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
+    // exchange item i = (row slot i / NV, value i % NV): items tid + q * kThreads of a thread are the same every step
+    constexpr int kG = 4;  // granules in flight per thread and round
+    const int NV = md.obs_dim + 2;  // state dims, running total, terminated flag
+    int xs[kG], xv[kG];
+#pragma unroll
+    for (int q = 0; q < kG; ++q) {
+        const int i = tid + q * kThreads;
+        xs[q] = i < ROWS * NV ? i / NV : -1;
+        xv[q] = i < ROWS * NV ? i - (i / NV) * NV : 0;
+    }
     {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
         // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
         const int nlv = deterministic ? 0 : lv_rows * md.out_dim;
@@ -837,6 +959,14 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     };
 
+    Pre pre;      // chunk-0 weight fragments + biases of the NEXT linear op of this wave (kPre kernels)
+    NextOp cur_op;  // ... and that op's descriptor
+    cur_op.valid = false;
+    if constexpr (kPre) {
+        const int m0 = fast ? __builtin_amdgcn_readfirstlane(sm.sched[ra.t_begin]) : domain;
+        cur_op = describe_layer<R, S>(md, sm.lmeta, 0, m0, wave);
+        prefetch_issue(cur_op, lane, pre);
+    }
     {   // the first step's actions are in flight while the state / totals / flags are fetched: one round trip for all of it
         // (the per-step launches of EXACT / DEVICE mode pay this prologue every step)
         float av[kPrefetch];
@@ -869,8 +999,19 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             float* nxt = sm.buf1;
             for (int l = 0; l < md.n_layers; ++l) {
                 prof.mark(12);
-                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
-                __syncthreads();
+                if constexpr (kPre) {
+                    NextOp nop;
+                    nop.valid = false;
+                    if (l + 1 < md.n_layers) nop = describe_layer<R, S>(md, sm.lmeta, l + 1, member, wave);
+                    else if (t + 1 < ra.t_end)  // the next step's first op (its member: the schedule's next entry / the same domain)
+                        nop = describe_layer<R, S>(md, sm.lmeta, 0, fast ? __builtin_amdgcn_readfirstlane(sm.sched[t + 1]) : domain, wave);
+                    mlp_layer_pre<R, S>(md, l + 1 == md.n_layers, cur_op, cur, nxt, wave, lane, prof, pre, nop);
+                    cur_op = nop;
+                    lds_barrier();
+                } else {
+                    mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                    __syncthreads();
+                }
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
@@ -990,16 +1131,18 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 
         if (more && persist) {
             // ---- hand the rows over: publish what this workgroup computed, become the owner of other rows, collect them ----
-            const int NV = md.obs_dim + 2;  // state dims, running total, terminated flag
             const unsigned long long tag = (unsigned long long)(t + 1) << 32;
-            for (int i = tid; i < ROWS * NV; i += kThreads) {
-                const int s = i / NV, v = i - s * NV;
+            auto publish_item = [&](const int s, const int v) __attribute__((always_inline)) {
                 const int rid = sm.rowid[s];
-                if (rid < 0) continue;
+                if (rid < 0) return;
                 const unsigned bits = v < md.obs_dim ? __float_as_uint(sm.state[s * md.obs_dim + v])
                                                      : (v == md.obs_dim ? __float_as_uint(sm.tot[s]) : (unsigned)sm.term[s]);
                 __hip_atomic_store(ra.exchange + (size_t)rid * NV + v, tag | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1, 8 B
-            }
+            };
+#pragma unroll
+            for (int q = 0; q < kG; ++q)
+                if (xs[q] >= 0) publish_item(xs[q], xv[q]);
+            for (int i = tid + kG * kThreads; i < ROWS * NV; i += kThreads) publish_item(i / NV, i - (i / NV) * NV);  // very wide states
             __syncthreads();  // everyone has read rowid / state / tot / term of the old rows
             {
                 const int j0 = (wg % ra.groups) * ROWS;
@@ -1014,19 +1157,20 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             compute_act_base();
             float av2[kPrefetch];
             fetch_actions_issue(t + 1, av2);  // in flight while the rows arrive
-            constexpr int kG = 4;            // granules in flight per thread and round
-            for (int base = tid; base < ROWS * NV; base += kG * kThreads) {
+            for (int base = 0; base < ROWS * NV; base += kG * kThreads) {
                 const unsigned long long* src[kG];
                 unsigned long long g[kG];
+                int gs[kG], gv[kG];
 #pragma unroll
                 for (int q = 0; q < kG; ++q) {
-                    const int i = base + q * kThreads;
+                    const int i = base + tid + q * kThreads;
+                    gs[q] = base == 0 ? xs[q] : (i < ROWS * NV ? i / NV : -1);
+                    gv[q] = base == 0 ? xv[q] : (i < ROWS * NV ? i - (i / NV) * NV : 0);
                     src[q] = nullptr;
                     g[q] = tag;  // rows of the padding: zero state, total, flag
-                    if (i < ROWS * NV) {
-                        const int s = i / NV, v = i - s * NV;
-                        const int rid = sm.rowid[s];
-                        if (rid >= 0) src[q] = ra.exchange + (size_t)rid * NV + v;
+                    if (gs[q] >= 0) {
+                        const int rid = sm.rowid[gs[q]];
+                        if (rid >= 0) src[q] = ra.exchange + (size_t)rid * NV + gv[q];
                     }
                 }
                 for (int spins = 0;; ++spins) {
@@ -1046,16 +1190,13 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     __builtin_amdgcn_s_sleep(8);
                 }
 #pragma unroll
-                for (int q = 0; q < kG; ++q) {
-                    const int i = base + q * kThreads;
-                    if (i < ROWS * NV) {
-                        const int s = i / NV, v = i - s * NV;
+                for (int q = 0; q < kG; ++q)
+                    if (gs[q] >= 0) {
                         const unsigned bits = (unsigned)g[q];
-                        if (v < md.obs_dim) sm.state[s * md.obs_dim + v] = __uint_as_float(bits);
-                        else if (v == md.obs_dim) sm.tot[s] = __uint_as_float(bits);
-                        else sm.term[s] = (int)bits;
+                        if (gv[q] < md.obs_dim) sm.state[gs[q] * md.obs_dim + gv[q]] = __uint_as_float(bits);
+                        else if (gv[q] == md.obs_dim) sm.tot[gs[q]] = __uint_as_float(bits);
+                        else sm.term[gs[q]] = (int)bits;
                     }
-                }
             }
             for (int s = tid; s < ROWS; s += kThreads) sm.lrew[s] = 0.f;
             fetch_actions_commit(t + 1, av2);
