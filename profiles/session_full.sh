@@ -1,0 +1,17 @@
+#!/bin/bash
+# The round's evidence session on the GPU box: smoke, the whole GPU test suite, the rocprofv3 collection, the default bench line,
+# the N = 2 path on one GPU (gloo).  bash profiles/session_full.sh <tag>
+set -u
+TAG=${1:-r2}
+export TMPDIR=/tmp
+OUT=gpurun_out/full_$TAG
+mkdir -p $OUT
+run() { name=$1; shift; echo "== $name: $*" ; ( time timeout ${TMO:-1200} "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)"; }
+run smoke python -c "import __graft_entry__ as g; g.smoke()"
+run tests python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider
+run bench python bench.py
+grep -h '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json
+HIPETS_DIST_BACKEND=gloo run bench_gloo2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2
+grep -h '"metric"' $OUT/bench_gloo2.log | tail -1 > $OUT/bench_line_gloo2.json
+run collect bash profiles/collect.sh $TAG
+echo done
