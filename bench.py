@@ -238,6 +238,9 @@ def main():
                 pass
         else:
             sharded = "torch.distributed"  # gloo: several ranks on one GPU, per-iteration all-gather through the host
+            # ranks SHARE a GPU here: their kernels compete for the CUs, so the one-launch form of DEVICE mode (which needs all of
+            # its workgroups resident at once) is off; with one process per GPU (the nccl path) it stays on
+            engine.set_persistent(False)
 
     def barrier():
         if world > 1:

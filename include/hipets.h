@@ -183,9 +183,17 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
 /* DEVICE-mode rollouts with a fresh permutation per step (random_model) run as ONE persistent launch when all their
  * workgroups are co-resident (<= one per CU): rows change workgroups every step through a table of 8-byte {value, step tag}
  * granules in HBM (write-through stores, polled loads; no grid barrier).  Larger batches launch once per step.  Every poll is
- * bounded: if a producer never shows up the kernel raises a host-visible flag, the NEXT call on the engine fails with that
- * report and the engine falls back to per-step launches.  on = 0 forces per-step launches (also: env HIPETS_NO_PERSISTENT=1). */
+ * bounded (0.2 s): if a producer never shows up the kernel raises a host-visible flag, the NEXT call on the engine fails with
+ * that report and the engine falls back to per-step launches.  The persistent form assumes what the reference's deployment
+ * gives it -- one planning process per GPU; processes or streams that share a GPU with other large kernels must switch it
+ * off: on = 0 forces per-step launches (also: env HIPETS_NO_PERSISTENT=1).                                               */
 int hipets_set_persistent(hipets_engine* e, int32_t on);
+
+/* Launches with fewer one-tile workgroups than CUs (cfg1 cartpole, a rank's shard of a strong-scaled plan, PlaNet at pop
+ * 1000) use 16-wave workgroups -- one column tile per wave -- where a shape-specialised instance exists; on = 0 keeps the
+ * 4-wave kernels everywhere (also: env HIPETS_NO_WIDE=1).  Results differ from the 4-wave kernel's only by the summation
+ * order of waves that own a single unit (last-bit level).                                                              */
+int hipets_set_wide_workgroups(hipets_engine* e, int32_t on);
 
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {

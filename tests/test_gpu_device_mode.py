@@ -133,3 +133,93 @@ def test_persistent_and_per_step_launches_agree_bitwise(engine, case):
     finally:
         engine.set_persistent(True)
     assert torch.equal(a, b)
+
+
+def test_error_behaviour_of_the_round2_entry_points(engine):
+    """Plan mode / trace / batched-plan misuse fails with a message, never silently: non-zero C return -> HipetsError."""
+    from hipets.planning import _BoundObjective
+
+    obs, act, H, P, pop = 17, 6, 5, 5, 40
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=32, seed=1)
+    spec = to_spec(om, obs, act)
+    engine.set_model(spec)
+    with pytest.raises(ValueError, match="plan mode"):
+        engine.set_plan_mode("exact")
+    with pytest.raises(ValueError, match="perms / eps / members must be None"):
+        engine.rollout(torch.zeros(pop, H, act, device=DEV), np.zeros(obs, np.float32), P, mode="device",
+                       eps=torch.zeros(H, pop * P, obs, device=DEV))
+    with pytest.raises(hipets.HipetsError, match="multiple of the number of models"):  # gaussian_mlp.py:195-200 in DEVICE mode too
+        engine.rollout(torch.zeros(3, H, act, device=DEV), np.zeros(obs, np.float32), 4, mode="device")
+    # a trace too small for the plan is reported by the plan call
+    fn = hipets.make_eval_fn(spec, P, engine=engine, seed=1, mode="device")
+    lb, ub = [[-1.0] * act] * H, [[1.0] * act] * H
+    opt = hipets.CEMOptimizer(2, 0.1, pop, lb, ub, 0.1, DEV, return_mean_elites=True, seed=1)
+    engine.set_plan_trace(2, pop - 1, H, act, int(opt.elite_num))
+    try:
+        with pytest.raises(hipets.HipetsError, match="plan trace"):
+            opt.optimize(_BoundObjective(fn, np.zeros(obs, np.float32)), x0=torch.zeros(H, act))
+    finally:
+        engine.set_plan_trace(0)
+    # batched plans run FAST-mode rollouts only: a DEVICE-mode objective is refused by the agent, the mode by the library
+    with pytest.raises(ValueError, match="FAST rollout path"):
+        hipets.BatchedMPPIAgent(fn, 2, [-1.0] * act, [1.0] * act, H, 2, pop, 0.9, 1.0, 0.9)
+    engine.set_plan_mode("device")
+    try:
+        with pytest.raises(hipets.HipetsError, match="batched planning"):
+            engine.plan_cem(opt._params, torch.zeros(2, H, act, device=DEV), opt.lower_bound, opt.upper_bound,
+                            np.zeros((2, obs), np.float32), P, n_env=2)
+    finally:
+        engine.set_plan_mode("fast")
+    # the persistent switch is reversible and DEVICE rollouts work either way (covered bit for bit elsewhere)
+    engine.set_persistent(False)
+    engine.set_persistent(True)
+
+
+def test_fast_mode_statistics_match_reference_semantics_at_cfg2_size(engine):
+    """SURVEY 8c T5 at BASELINE size: FAST mode's block-balanced member schedule against DEVICE mode (the reference's global
+    balanced permutation per step) on the cfg2 batch (pop 500 x 20 particles x H 30), 32 seeds each.  Per candidate the two
+    estimators of the expected return agree within 3 sigma-equivalents (max |z| over 500 candidates < 4.5, mean z ~ 0), and
+    so do the across-seed variances (ratio within the F-distribution's range for 31 / 31 degrees of freedom)."""
+    obs, act, pop, P, H, seeds = 17, 6, 500, 20, 30, 32
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0)
+    engine.set_model(to_spec(om, obs, act))
+    g = torch.Generator().manual_seed(3)
+    actions = (torch.rand(pop, H, act, generator=g) * 2 - 1).to(DEV)
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+    runs = {}
+    for mode in ("fast", "device"):
+        runs[mode] = torch.stack([engine.rollout(actions, s0, P, mode=mode, seed=100 + i, stream_id=i) for i in range(seeds)]).double().cpu()
+    mf, md_ = runs["fast"].mean(0), runs["device"].mean(0)
+    vf, vd = runs["fast"].var(0), runs["device"].var(0)
+    z = (mf - md_) / torch.sqrt(vf / seeds + vd / seeds)
+    assert z.abs().max() < 4.5, float(z.abs().max())
+    assert abs(float(z.mean())) < 0.25
+    ratio = (vf / vd)
+    assert 0.2 < float(ratio.median()) < 5.0 and float(ratio.log().mean().abs()) < 0.35  # no systematic variance inflation / deflation
+    # balance of the FAST schedule per step, like tests/core/test_models.py:116-131
+    nwg, _ = engine.fast_geometry(pop, P, H)
+    sched = engine.fast_schedule(H, nwg, 100, 0).cpu()
+    for t in range(H):
+        c = torch.bincount(sched[t].long(), minlength=5)
+        assert c.max() - c.min() <= 1
+
+
+def test_wide_workgroups_for_small_batches(engine):
+    """Launches with fewer one-tile workgroups than CUs (cfg1 cartpole; a rank's shard of a strong-scaled cfg2 plan) run the
+    16-wave variant of the shape-specialised kernels: same returns as the oracle (T2), and as the 4-wave kernel up to the
+    summation order of single-unit waves (1e-5 relative)."""
+    for (obs, act, pop, P, H, mkw) in [SIZES[1], (17, 6, 63, 20, 30, dict(ensemble_size=5, hid=200))]:
+        om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+        engine.set_model(to_spec(om, obs, act))
+        for mode in ("fast", "device"):
+            wide = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=5, stream_id=2)
+            engine.set_wide_workgroups(False)
+            try:
+                narrow = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=5, stream_id=2)
+            finally:
+                engine.set_wide_workgroups(True)
+            assert torch.allclose(wide, narrow, rtol=1e-5, atol=1e-5), (mode, float((wide - narrow).abs().max()))
+        # against the oracle (DEVICE mode: exported permutations and eps)
+        out = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=5, stream_id=2)
+        ref = po.rollout(om, actions, s0, P, perms=engine.device_perms(H, pop * P, 5, 2).cpu(), eps=engine.fast_normals(H, pop * P, 5, 2).cpu())
+        assert_returns_close(out, ref)
