@@ -189,12 +189,6 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
  * off: on = 0 forces per-step launches (also: env HIPETS_NO_PERSISTENT=1).                                               */
 int hipets_set_persistent(hipets_engine* e, int32_t on);
 
-/* Launches with fewer one-tile workgroups than CUs (cfg1 cartpole, a rank's shard of a strong-scaled plan, PlaNet at pop
- * 1000) use 16-wave workgroups -- one column tile per wave -- where a shape-specialised instance exists; on = 0 keeps the
- * 4-wave kernels everywhere (also: env HIPETS_NO_WIDE=1).  Results differ from the 4-wave kernel's only by the summation
- * order of waves that own a single unit (last-bit level).                                                              */
-int hipets_set_wide_workgroups(hipets_engine* e, int32_t on);
-
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {
     int32_t population_size;

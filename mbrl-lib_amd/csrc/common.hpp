@@ -4,21 +4,14 @@
 #include <stdint.h>
 #include "../../include/hipets.h"
 
-// Build variants of the device code (waves per workgroup, HIPETS_WAVES) live in their own inline namespace so that several of
-// them can be linked into one library: the default 4-wave code is hipets::w4::*, the 16-wave small-batch variant hipets::w16::*.
-#ifndef HIPETS_WAVES
-#define HIPETS_WAVES 4
-#endif
-#ifndef HIPETS_NS
-#define HIPETS_NS w4
-#endif
-
 namespace hipets {
-inline namespace HIPETS_NS {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kWave = 64;          // CDNA wavefront
+#ifndef HIPETS_WAVES
+#define HIPETS_WAVES 4
+#endif
 constexpr int kWaves = HIPETS_WAVES;  // waves per workgroup: 4 = one per SIMD (measured best on cfg2: 1.27 ms/rollout);
                                       // 8 = two per SIMD builds and passes parity but measured 1.31 ms (VALU phases
                                       // are shared by the SIMD partners and the kernel is capped at 256 VGPRs)
@@ -132,5 +125,4 @@ __host__ __device__ inline uint32_t perm_apply(uint32_t x, uint32_t n, uint32_t 
     return x;
 }
 
-}  // inline namespace HIPETS_NS
 }  // namespace hipets

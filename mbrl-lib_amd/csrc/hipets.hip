@@ -80,7 +80,6 @@ struct hipets_engine {
     DevBuf exchange, step_keys;
     int* error_flag = nullptr;
     bool persistent_ok = true;
-    bool wide_ok = true;  // 16-wave workgroups for launches with fewer one-tile workgroups than CUs (HIPETS_NO_WIDE=1 disables)
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
     // RCCL communicator (lazy-loaded librccl)
@@ -120,14 +119,7 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
     }
     hipError_t err;
     switch (R) {
-        case 1:
-            // few one-tile workgroups (cfg1, a rank's shard of a strong-scaled plan): CUs idle anyway, so spend 16 waves on each
-            // workgroup -- one column tile per wave, the per-layer MFMA chain is 4x shorter.  Only shape-specialised instances
-            // exist for that width; anything else (hipErrorNotSupported) takes the 4-wave kernel.
-            err = hipErrorNotSupported;
-            if (e->wide_ok && grid <= e->num_cu) err = launch_rollout_r1_w16(grid, (unsigned)lds, (int)e->lds_max, &e->md, &ra, st, a, b);
-            if (err == hipErrorNotSupported) err = launch_rollout_r1(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b);
-            break;
+        case 1: err = launch_rollout_r1(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
         case 2: err = launch_rollout_r2(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
         case 3: err = launch_rollout_r3(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
         case 4: err = launch_rollout_r4(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
@@ -327,8 +319,6 @@ int hipets_create(int device, hipets_engine** out) {
     if (e->error_flag) *e->error_flag = 0;
     const char* np = std::getenv("HIPETS_NO_PERSISTENT");
     e->persistent_ok = e->error_flag != nullptr && !(np && np[0] == '1');
-    const char* nw = std::getenv("HIPETS_NO_WIDE");
-    e->wide_ok = !(nw && nw[0] == '1');
     *out = e;
     return 0;
 }
@@ -809,12 +799,6 @@ int hipets_set_persistent(hipets_engine* e, int32_t on) {
     return 0;
 }
 
-int hipets_set_wide_workgroups(hipets_engine* e, int32_t on) {
-    if (!e) return fail("null engine");
-    e->wide_ok = on != 0;
-    return 0;
-}
-
 int hipets_set_plan_trace(hipets_engine* e, const hipets_plan_trace* t) {
     if (!e) return fail("null engine");
     e->has_trace = t != nullptr;
@@ -1249,8 +1233,7 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     ra.trace_rewards = o->trace_rewards;
     const size_t lds = planet_smem_bytes(e->pd.ld);
     const int nwg = (int)((B + kTile - 1) / kTile);
-    if (e->wide_ok && nwg <= e->num_cu) HCHECK(launch_planet_rollout_w16(nwg, (unsigned)lds, (int)e->lds_max, &e->pd, &ra, st));
-    else HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st));
+    HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st));
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
     return 0;

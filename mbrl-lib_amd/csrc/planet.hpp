@@ -21,7 +21,6 @@
 #include "rollout.hpp"
 
 namespace hipets {
-inline namespace HIPETS_NS {
 
 __device__ __forceinline__ float sigmoid_hw(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 // tanh(x) = 2 sigmoid(2x) - 1 (hardware exp2 / rcp, ~1e-7 absolute)
@@ -149,5 +148,4 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
     if (tid < kTile && rowid[tid] >= 0) ra.totals[rowid[tid]] = tot[tid];
 }
 
-}  // inline namespace HIPETS_NS
 }  // namespace hipets

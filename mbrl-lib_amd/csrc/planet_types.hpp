@@ -3,7 +3,6 @@
 #include "rollout.hpp"
 
 namespace hipets {
-inline namespace HIPETS_NS {
 
 constexpr int kPlanetOps = 8;
 enum { PL_EMBED = 0, PL_GI = 1, PL_GH = 2, PL_PRIOR1 = 3, PL_PRIOR2 = 4, PL_REW1 = 5, PL_REW2 = 6, PL_REW3 = 7 };
@@ -48,5 +47,4 @@ __host__ __device__ inline size_t planet_smem_bytes(int ld) {
     return (size_t)kTile * ld * 4 + 2 * kTile * 4 + sizeof(PlanetOp) * kPlanetOps;
 }
 
-}  // inline namespace HIPETS_NS
 }  // namespace hipets

@@ -25,9 +25,6 @@
 #include "common.hpp"
 
 namespace hipets {
-inline namespace HIPETS_NS {
-
-constexpr int kMaxWavesAny = 16;  // widest workgroup of any build variant: LDS sizes must not depend on the variant
 
 struct LayerMeta {
     int Kp, Np;          // K, N padded to multiples of 16
@@ -662,7 +659,7 @@ struct RolloutSmem {
     int* nodelta;    // [obs_dim]
     int* sched;      // [H] member slot of this workgroup per step (FAST)
     LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
-    long long* prof;   // [waves][16] phase-cycle accumulators (profiling aid; sized for the widest workgroup variant)
+    long long* prof;   // [kWaves][16] phase-cycle accumulators (profiling aid)
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
@@ -680,7 +677,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += align16((size_t)obs_dim * 4);
     n += align16((size_t)horizon * 4);
     n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
-    n += align16((size_t)kMaxWavesAny * 16 * 8);
+    n += align16((size_t)kWaves * 16 * 8);
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
@@ -744,7 +741,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
-        sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kMaxWavesAny * 16 * 8);
+        sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
@@ -1219,7 +1216,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         ra.totals[rid] = sm.tot[s];
         if ((!fast && !persist) || (!kLean && ra.write_back)) ra.term[rid] = (unsigned char)sm.term[s];
     }
-    if (prof.on && wave < 8) {  // flush the phase accumulators of this wave (the caller's buffer holds 8 waves)
+    if (prof.on) {  // flush the phase accumulators of this wave
 #pragma unroll
         for (int i = 0; i < 16; ++i) ra.phase_cycles[wave * 16 + i] += prof.slot[i];
     }
@@ -1232,5 +1229,4 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     }
 }
 
-}  // inline namespace HIPETS_NS
 }  // namespace hipets

@@ -107,7 +107,6 @@ SYMBOLS = {
     "hipets_device_perms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_set_plan_mode": (C.c_int, [_P, C.c_int32]),
     "hipets_set_persistent": (C.c_int, [_P, C.c_int32]),
-    "hipets_set_wide_workgroups": (C.c_int, [_P, C.c_int32]),
     "hipets_set_plan_trace": (C.c_int, [_P, C.POINTER(PlanTrace)]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -305,10 +305,6 @@ class Engine:
         """Allow (default) or forbid the persistent one-launch form of DEVICE-mode rollouts (hipets_set_persistent)."""
         _lib.check(self._lib.hipets_set_persistent(self._h, int(bool(on))))
 
-    def set_wide_workgroups(self, on: bool = True):
-        """Allow (default) or forbid the 16-wave workgroup variant for launches with few one-tile workgroups."""
-        _lib.check(self._lib.hipets_set_wide_workgroups(self._h, int(bool(on))))
-
     def set_plan_trace(self, iters: int = 0, max_rows: int = 0, horizon: int = 0, act_dim: int = 0, elite_num: int = 0, n_env: int = 1):
         """Record the following fused plans iteration by iteration (hipets_set_plan_trace); returns the dict of device
         tensors the library writes into.  ``iters=0`` switches recording off.  ``max_rows`` counts the candidates of ALL

@@ -203,23 +203,3 @@ def test_fast_mode_statistics_match_reference_semantics_at_cfg2_size(engine):
         c = torch.bincount(sched[t].long(), minlength=5)
         assert c.max() - c.min() <= 1
 
-
-def test_wide_workgroups_for_small_batches(engine):
-    """Launches with fewer one-tile workgroups than CUs (cfg1 cartpole; a rank's shard of a strong-scaled cfg2 plan) run the
-    16-wave variant of the shape-specialised kernels: same returns as the oracle (T2), and as the 4-wave kernel up to the
-    summation order of single-unit waves (1e-5 relative)."""
-    for (obs, act, pop, P, H, mkw) in [SIZES[1], (17, 6, 63, 20, 30, dict(ensemble_size=5, hid=200))]:
-        om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
-        engine.set_model(to_spec(om, obs, act))
-        for mode in ("fast", "device"):
-            wide = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=5, stream_id=2)
-            engine.set_wide_workgroups(False)
-            try:
-                narrow = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=5, stream_id=2)
-            finally:
-                engine.set_wide_workgroups(True)
-            assert torch.allclose(wide, narrow, rtol=1e-5, atol=1e-5), (mode, float((wide - narrow).abs().max()))
-        # against the oracle (DEVICE mode: exported permutations and eps)
-        out = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=5, stream_id=2)
-        ref = po.rollout(om, actions, s0, P, perms=engine.device_perms(H, pop * P, 5, 2).cpu(), eps=engine.fast_normals(H, pop * P, 5, 2).cpu())
-        assert_returns_close(out, ref)
