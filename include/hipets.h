@@ -59,6 +59,11 @@ enum { HIPETS_NORM_NONE = 0, HIPETS_NORM_F32 = 1, HIPETS_NORM_F64 = 2 };
  * GaussianMLPs (conf/dynamics_model/basic_ensemble.yaml): every row draws its member independently
  * (basic_ensemble.py:122-129, 255-260), any batch size, no elites (:262-266), per-member logvar bounds. */
 enum { HIPETS_ENSEMBLE_GAUSSIAN_MLP = 0, HIPETS_ENSEMBLE_BASIC = 1 };
+/* arithmetic of the ensemble MLP's linear layers */
+enum { HIPETS_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: fp32 operands, fp32 accumulate (the graded mode)              */
+       HIPETS_PREC_BF16X3 = 1  /* fp32 operands carried as three bf16 pieces, six exact partial products per product     */
+                               /* on v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32-accurate to a few product ulps      */
+                               /* (|error| <= 2^-22 |a||b| per product), reported SEPARATELY from the fp32-MFMA mode     */ };
 /* randomness source of a rollout */
 enum { HIPETS_MODE_EXACT = 0,  /* reference semantics, injected perms / eps (parity mode)                              */
        HIPETS_MODE_FAST = 1,   /* whole-horizon kernel, block-balanced member schedule, in-kernel Philox             */
@@ -102,6 +107,8 @@ typedef struct {
     const void* const* weights; /* HOST array [n_layers] of DEVICE float [E, in_l, out_l]         */
     const void* const* biases;  /* HOST array [n_layers] of DEVICE float [E, 1, out_l]            */
     int32_t ensemble_kind;   /* HIPETS_ENSEMBLE_*                                                 */
+    int32_t precision;       /* HIPETS_PREC_*: BF16X3 runs only where a shape-specialised kernel instance   */
+                             /*   exists for the model and the call (else the rollout call fails)           */
 } hipets_model_desc;
 
 /* options of one evaluate_action_sequences call */

@@ -73,6 +73,7 @@ struct hipets_engine {
     bool has_model = false;
     ModelDev md{};
     int ensemble_size = 0;
+    DevBuf w3pack;  // bf16x3 precision mode: weight pieces
     DevBuf wpack, bpack, layer_meta, norm_mean, norm_std, min_lv, max_lv, no_delta, members;
     // rollout workspace
     DevBuf s0, state, totals, term, schedule, plan_schedule;
@@ -126,6 +127,9 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
         default: return fail("unsupported rows_per_group %d (1..%d)", R, kMaxR);
     }
     if (timed) e->events.emplace_back(a, b);  // recorded (or leaked to the pool) either way
+    if (err == hipErrorNotSupported && e->md.precision == HIPETS_PREC_BF16X3)
+        return fail("precision bf16x3: no shape-specialised kernel instance for this model / call (SiLU, f64 normaliser, no obs "
+                    "preprocessing, in-kernel sampling, one of the BASELINE layer shapes, R = %d); use precision f32", R);
     if (err != hipSuccess) return fail("rollout kernel launch failed: %s", hipGetErrorString(err));
     return 0;
 }
@@ -327,7 +331,7 @@ void hipets_destroy(hipets_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
-    for (DevBuf* b : {&e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
+    for (DevBuf* b : {&e->w3pack, &e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
                       &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->mu, &e->disp, &e->population, &e->values,
                       &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered})
         b->release();
@@ -391,6 +395,18 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         boff += lms[l].Np;
         maxK = std::max(maxK, std::max(lms[l].Kp, lms[l].Np));
     }
+    md.precision = d->precision;
+    if (d->precision != HIPETS_PREC_F32 && d->precision != HIPETS_PREC_BF16X3) return fail("unknown precision %d", d->precision);
+    long long w3off = 0;  // 16-byte units
+    int max_kc32 = 1;
+    for (int l = 0; l < d->n_layers; ++l) {
+        lms[l].Kp32 = (Ks[l] + 31) / 32 * 32;
+        lms[l].pad_ = 0;
+        lms[l].woff3 = w3off;
+        w3off += (long long)(lms[l].Np / 16) * (lms[l].Kp32 / 32) * 3 * 64;
+        max_kc32 = std::max(max_kc32, lms[l].Kp32 / 32);
+    }
+    md.w3member = w3off;
     md.Kp0 = lms[0].Kp;
     md.hidC = up16(d->hid) / kTile;
     md.outC = up16(md.out_total) / kTile;
@@ -399,11 +415,20 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     // row stride: >= widest activation, == 8 (mod 64) floats => conflict-free ds_read_b128 A fragments
     int ld = maxK;
     while (ld % 64 != 8) ld += 4;
+    if (d->precision == HIPETS_PREC_BF16X3) {
+        // activation rows hold [k chunk of 32][3 pieces][32 x bf16] = 192 bytes per chunk; the last layer's fp32 results share the
+        // rows; a byte stride that is an ODD multiple of 16 keeps the ds_read_b128 of 16 consecutive rows on distinct slots
+        int ldb = std::max(max_kc32 * 192, lms[d->n_layers - 1].Np * 4);
+        ldb = (ldb + 15) / 16 * 16;
+        if ((ldb / 16) % 2 == 0) ldb += 16;
+        ld = ldb / 4;
+    }
     md.ld = ld;
     if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, 64,
                            md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows) > e->lds_max)
         return fail("model too wide for LDS (ld=%d)", md.ld);
 
+    if (d->precision == HIPETS_PREC_BF16X3 && e->w3pack.ensure((size_t)md.w3member * md.M * 16)) return 1;
     if (e->wpack.ensure((size_t)md.wmember * md.M * 4)) return 1;
     if (e->bpack.ensure((size_t)md.bmember * md.M * 4)) return 1;
     if (e->members.ensure((size_t)md.M * 4)) return 1;
@@ -416,6 +441,13 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
                            reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp,
                            lms[l].Np, md.wmember, lms[l].woff, l < d->n_layers - 1 ? 1 : 0, 0);
         HCHECK(hipGetLastError());
+        if (d->precision == HIPETS_PREC_BF16X3) {
+            const long long n3 = (long long)(lms[l].Np / 16) * (lms[l].Kp32 / 32) * 3 * 64 * md.M;
+            hipLaunchKernelGGL(pack_weights_b3_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, e->w3pack.as<uint4>(),
+                               reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp32, lms[l].Np,
+                               md.w3member, lms[l].woff3, 0);
+            HCHECK(hipGetLastError());
+        }
         const int nb = md.M * lms[l].Np;
         hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
                            reinterpret_cast<const float*>(d->biases[l]), e->members.as<int>(), md.M, Ns[l], lms[l].Np, md.bmember,
@@ -442,6 +474,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     HCHECK(hipMemcpyAsync(e->no_delta.p, nd.data(), (size_t)d->obs_dim, hipMemcpyHostToDevice, st));
     HCHECK(hipStreamSynchronize(st));  // host staging buffers (nd, caller arrays) may go away after return
     md.layers = e->layer_meta.as<LayerMeta>();
+    md.w3 = e->w3pack.as<uint4>();
     md.w = e->wpack.as<float>();
     md.b = e->bpack.as<float>();
     md.norm_mean = e->norm_mean.as<double>();

@@ -31,6 +31,10 @@ struct LayerMeta {
     int boff;            // float offset of the layer's bias inside a member block
     int tail_steps;      // MFMA k-steps (of 4) of the last chunk that hold real weights: ceil((K - (Kp - 16)) / 4)
     long long woff;      // float offset of the layer's packed weights inside a member block
+    // bf16x3 precision mode (fp32 operands as three bf16 pieces on the bf16 matrix pipe):
+    int Kp32;            // K padded to a multiple of 32 (one v_mfma_f32_16x16x32_bf16 k-chunk)
+    int pad_;
+    long long woff3;     // 16-byte-unit offset of the layer's packed bf16 planes inside a member block
 };
 
 struct Extras {  // up to kMaxExtras leftover (column tile, row tile) units of one wave
@@ -59,6 +63,9 @@ struct ModelDev {
     int lv_rows;          // 1 (bounds shared by the members) or M (BasicEnsemble: one row per member)
     int iid_members;      // BasicEnsemble: members are drawn independently (no balanced shuffle, no batch % M rule)
     const unsigned char* no_delta;  // [obs_dim]
+    int precision;            // HIPETS_PREC_*
+    long long w3member;       // 16-byte units per member (bf16x3 planes)
+    const uint4* w3;          // packed bf16 planes: [member][layer][col tile][k chunk of 32][plane 0..2][lane][8 x bf16]
 };
 
 struct RolloutArgs {
@@ -486,6 +493,216 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 precision mode ("f32 on the bf16 matrix pipe").  An fp32 operand x is carried as three bf16 pieces x0 + x1 + x2
+// (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): |x - x0 - x1 - x2| <= 2^-24 |x|), and a product a b is formed from
+// the six partial products of weight <= 2^-16: a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0), each EXACT in fp32
+// (8 x 8 significand bits), accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The dropped terms (a1 b2, a2 b1, a2 b2) are
+// <= 2^-23 |a b|: the result is fp32-accurate to a few ulps of the products, at 6 x 17 cycles per 16x16x32 block instead of
+// 8 x 32 cycles for the fp32 MFMAs -- and the bf16 matrix pipe, unlike the fp32 one, runs beside the VALU.
+// Layouts: weights packed per (column tile, 32-wide k chunk, piece) as one A-operand fragment (lane l: output column
+// l & 15, k = 8 (l >> 4) .. + 7); activations in LDS per row as [k chunk][piece][4 groups][8 x bf16] so that a lane's
+// B-operand fragment of a piece is ONE ds_read_b128.  The last layer's results stay fp32 (sampling reads them).
+// ---------------------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// round-to-nearest-even bf16 of x as the upper 16 bits of a word (finite x)
+__host__ __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__host__ __device__ __forceinline__ float bits_to_float(unsigned u) {
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// the three pieces of x as bf16 bit patterns (in the UPPER halves of h[0..2])
+__host__ __device__ __forceinline__ void split3(float x, unsigned (&h)[3]) {
+    h[0] = bf16_rne_bits(x);
+    const float r1 = x - bits_to_float(h[0]);
+    h[1] = bf16_rne_bits(r1);
+    const float r2 = r1 - bits_to_float(h[1]);
+    h[2] = bf16_rne_bits(r2);
+}
+// four consecutive values -> per piece one 8-byte word pair (4 x bf16, little endian: value 0 in the low half of word 0)
+__device__ __forceinline__ void split3x4(const f32x4 v, u32x2 (&out)[3]) {
+    unsigned h[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3(v[i], h[i]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        out[p][0] = (h[0][p] >> 16) | h[1][p];
+        out[p][1] = (h[2][p] >> 16) | h[3][p];
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) {
+    bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+// byte offset inside an activation row of the 4 consecutive columns k0 .. k0 + 3 (k0 % 4 == 0) of piece p
+__device__ __forceinline__ int b3_offset(int k0, int p) { return (k0 >> 5) * 192 + p * 64 + ((k0 & 31) >> 3) * 16 + (k0 & 7) * 2; }
+
+template <int R, int CT, int EX>
+struct GemmFragsB3 {
+    u32x4 w[CT > 0 ? CT : 1][3];   // weight pieces (A operand) of the strided column tiles
+    u32x4 wx[EX > 0 ? EX : 1][3];  // ... of the extra units
+    u32x4 a[R][3];                 // activation pieces (B operand) of the row tiles
+    u32x4 ax[EX > 0 ? EX : 1][3];
+};
+
+// One wave's share of a linear op in bf16x3 arithmetic: same unit decomposition as wave_gemm (CT strided column tiles x R row
+// tiles + EX extra units).  `in`: LDS activation pieces (byte stride ldb); hidden ops write the activated result as pieces into
+// `out`, the last op writes fp32 (float stride ldb / 4) for the sampling phase.
+template <int R, int CT, int EX, int ACT>
+__device__ __forceinline__ void wave_gemm_b3(const char* __restrict__ in, char* __restrict__ out, const int ldb, const uint4* __restrict__ W3,
+                                             const float* __restrict__ bias, const int KC32, const int c_first, const Extras ex,
+                                             const bool last_op, const int lane) {
+    constexpr int CTn = CT > 0 ? CT : 1;
+    constexpr int EXn = EX > 0 ? EX : 1;
+    f32x4 acc[CTn][R];
+    f32x4 accx[EXn];
+    const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
+    const int exr[kMaxExtras] = {ex.r0, ex.r1, ex.r2, ex.r3};
+    // weights: 16-byte units; (column tile c, chunk kk, piece p, lane) -> ((c * KC32 + kk) * 3 + p) * 64 + lane
+    unsigned woff[CTn], wxoff[EXn];
+    int axoff[EXn];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) woff[ct] = (unsigned)((c_first + kWaves * ct) * KC32 * 192 + lane);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        wxoff[e] = (unsigned)(exc[e] * KC32 * 192 + lane);
+        axoff[e] = exr[e] * 16 * ldb;
+    }
+    const char* ap = in + (lane & 15) * ldb + (lane >> 4) * 16;
+    // biases: the packed bias arrays serve the fp32 kernels, where hidden layers keep their columns permuted inside every group
+    // of 16 (position lds_col(n) holds column n; lds_col is an involution); here columns are natural
+    auto bias4 = [&](const int c) __attribute__((always_inline)) {
+        const int g = lane >> 4;
+        if (last_op) return *reinterpret_cast<const f32x4*>(bias + c * 16 + 4 * g);
+        const float* bp = bias + c * 16 + g;  // natural column 4 g + i sits at position 4 i + g
+        return f32x4{bp[0], bp[4], bp[8], bp[12]};
+    };
+#pragma unroll
+    for (int ct = 0; ct < CTn; ++ct) {
+        const f32x4 b = CT > 0 ? bias4(c_first + kWaves * ct) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[ct][r] = b;
+    }
+#pragma unroll
+    for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bias4(exc[e]) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](GemmFragsB3<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
+        const uint4* Wk = W3 + (size_t)kk * 192;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.w[ct][p] = *reinterpret_cast<const u32x4*>(Wk + woff[ct] + p * 64);
+#pragma unroll
+        for (int e = 0; e < EX; ++e)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.wx[e][p] = *reinterpret_cast<const u32x4*>(Wk + wxoff[e] + p * 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.a[r][p] = *reinterpret_cast<const u32x4*>(ap + r * 16 * ldb + kk * 192 + p * 64);
+#pragma unroll
+        for (int e = 0; e < EX; ++e)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.ax[e][p] = *reinterpret_cast<const u32x4*>(ap + axoff[e] + kk * 192 + p * 64);
+    };
+    // the six partial products of one unit, smallest weights first
+    auto unit = [&](const u32x4 (&w)[3], const u32x4 (&a)[3], f32x4& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[2]), as_bf16x8(a[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[1]), as_bf16x8(a[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[0]), as_bf16x8(a[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[1]), as_bf16x8(a[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[0]), as_bf16x8(a[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w[0]), as_bf16x8(a[0]), c, 0, 0, 0);
+    };
+    auto compute = [&](const GemmFragsB3<R, CT, EX>& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < R; ++r) unit(f.w[ct], f.a[r], acc[ct][r]);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) unit(f.wx[e], f.ax[e], accx[e]);
+    };
+    GemmFragsB3<R, CT, EX> f0, f1;
+    load(f0, 0);
+    int kk = 0;
+    for (; kk + 1 < KC32; kk += 2) {
+        load(f1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < KC32) load(f0, kk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk < KC32) compute(f0);
+
+    const int j = lane & 15, g4 = 4 * (lane >> 4);
+    auto silu4 = [](const f32x4 a) {
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        const f32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
+        const f32x2 lo = {a[0], a[1]}, hi = {a[2], a[3]};
+        f32x2 tl = lo * k, th = hi * k;
+        tl[0] = __builtin_amdgcn_exp2f(tl[0]); tl[1] = __builtin_amdgcn_exp2f(tl[1]);
+        th[0] = __builtin_amdgcn_exp2f(th[0]); th[1] = __builtin_amdgcn_exp2f(th[1]);
+        tl = tl + one; th = th + one;
+        tl[0] = __builtin_amdgcn_rcpf(tl[0]); tl[1] = __builtin_amdgcn_rcpf(tl[1]);
+        th[0] = __builtin_amdgcn_rcpf(th[0]); th[1] = __builtin_amdgcn_rcpf(th[1]);
+        const f32x2 yl = lo * tl, yh = hi * th;
+        return f32x4{yl[0], yl[1], yh[0], yh[1]};
+    };
+    static_assert(ACT == HIPETS_ACT_SILU, "bf16x3 instances exist for SiLU models");
+    auto store = [&](const f32x4 v, const int row, const int col0) __attribute__((always_inline)) {
+        if (last_op) {
+            *reinterpret_cast<f32x4*>(out + (size_t)row * ldb + col0 * 4) = v;  // fp32, natural columns (float stride ldb / 4)
+        } else {
+            u32x2 pc[3];
+            split3x4(silu4(v), pc);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(out + (size_t)row * ldb + b3_offset(col0, p)) = pc[p];
+        }
+    };
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < R; ++r) store(acc[ct][r], r * 16 + j, (c_first + kWaves * ct) * 16 + g4);
+#pragma unroll
+    for (int e = 0; e < EX; ++e) store(accx[e], exr[e] * 16 + j, exc[e] * 16 + g4);
+}
+
+// linear op with CS column tiles in bf16x3 arithmetic (static shapes only: the lean instances)
+template <int R, int ACT, int CS>
+__device__ __forceinline__ void linear_op_b3(const uint4* W3, const float* bias, const int KC32, const int ldb, const bool last_op, const char* in,
+                                             char* out, const int wave, const int lane) {
+    constexpr int kMaxCT = 3;
+    constexpr int full = CS / kWaves, rem = CS % kWaves, nu = rem * R;
+    static_assert(full <= kMaxCT, "bf16x3 instances cover ops of at most 15 column tiles");
+    Extras ex;
+    ex.c0 = kWaves * full + wave / R;                ex.r0 = wave % R;
+    ex.c1 = kWaves * full + (wave + kWaves) / R;     ex.r1 = (wave + kWaves) % R;
+    ex.c2 = kWaves * full + (wave + 2 * kWaves) / R; ex.r2 = (wave + 2 * kWaves) % R;
+    ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
+    constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
+    if constexpr (lo == hi) {
+        if constexpr (full > 0 || lo > 0) wave_gemm_b3<R, full, lo, ACT>(in, out, ldb, W3, bias, KC32, wave, ex, last_op, lane);
+    } else {
+        if (wave < nu % kWaves) {
+            wave_gemm_b3<R, full, hi, ACT>(in, out, ldb, W3, bias, KC32, wave, ex, last_op, lane);
+        } else {
+            if constexpr (full > 0 || lo > 0) wave_gemm_b3<R, full, lo, ACT>(in, out, ldb, W3, bias, KC32, wave, ex, last_op, lane);
+        }
+    }
+}
+
 // Compile-time facts of a rollout-kernel instance; -1 = decided at run time.  Instances with HIDC >= 0 are the
 // SHAPE-SPECIALISED ("lean") kernels of the BASELINE configurations: hidden / output column-tile counts, normaliser kind,
 // obs preprocessing, reward and termination functions and the launch mode are template arguments, and everything those
@@ -493,9 +710,10 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
 // per-member logvar bounds) is compiled out.  The host picks an instance only when the model and the call match ALL of its
 // facts (launch.hpp select_*); anything else runs the generic instance.  Same arithmetic, instruction for instruction, in
 // the parts both execute: tests compare the two bit for bit.
-template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1>
+template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1, int PREC_ = 0>
 struct KSpec {
     static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
+    static constexpr int PREC = PREC_;  // HIPETS_PREC_F32 (fp32 MFMA) or HIPETS_PREC_BF16X3 (lean instances only)
     static constexpr bool LEAN = HIDC_ >= 0;
 };
 
@@ -538,6 +756,19 @@ __device__ __forceinline__ void mlp_layer_pre(const ModelDev& md, const bool las
     lm.tail_steps = cur.tail_steps;
     if (!last_op) linear_op<R, S::ACT, S::HIDC, true>(cur.W, cur.bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, &pre, &nxt);
     else linear_op<R, S::ACT, S::OUTC, true>(cur.W, cur.bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof, &pre, &nxt);
+}
+
+// Layer l in bf16x3 arithmetic
+template <int R, class S>
+__device__ __forceinline__ void mlp_layer_b3(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member, const float* in, float* out,
+                                             const int wave, const int lane) {
+    const LayerMeta lm = lmeta[l];
+    const uint4* W3 = md.w3 + (size_t)member * md.w3member + lm.woff3;
+    const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
+    const char* inb = reinterpret_cast<const char*>(in);
+    char* outb = reinterpret_cast<char*>(out);
+    if (l < md.n_layers - 1) linear_op_b3<R, S::ACT, S::HIDC>(W3, bias, lm.Kp32 / 32, md.ld * 4, false, inb, outb, wave, lane);
+    else linear_op_b3<R, S::ACT, S::OUTC>(W3, bias, lm.Kp32 / 32, md.ld * 4, true, inb, outb, wave, lane);
 }
 
 // Layer l of the ensemble MLP with member `member`'s weights.
@@ -706,6 +937,8 @@ template <int R, class S>
 __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
     constexpr bool kLean = S::LEAN;
+    constexpr bool kB3 = S::PREC == HIPETS_PREC_BF16X3;  // operands as three bf16 pieces on the bf16 matrix pipe (lean instances)
+    static_assert(!kB3 || kLean, "bf16x3 arithmetic exists for the shape-specialised instances");
     // cross-layer weight prefetch (wave_gemm PRE): measured on MI355X and left OFF -- cfg2 FAST 1.054 ms with it (1.073 before
     // the descriptors were derived only once and the layer barriers stopped draining vmcnt) against 1.021 ms without: the
     // ~800-cycle first-fragment latency it hides is outweighed by 56 more live VGPRs and the extra scalar work between layers
@@ -905,7 +1138,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 
     // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0.
     // One item = (row, 4 consecutive columns): four independent LDS-read -> f64 normalise -> LDS-write chains.
-    const int kq = Kp0 >> 2;  // column quads per row (Kp0 is a multiple of 16)
+    const int kq = (kB3 ? sm.lmeta[0].Kp32 : Kp0) >> 2;  // column quads per row (the padded input width is a multiple of 16 / 32)
     // The (wave-uniform) normaliser / obs-preprocess switches are resolved ONCE per call into a compile-time variant:
     // with the switches inside, each of the four elements became its own chain of scalar branches and waits.
     auto build_input_impl = [&](const int t, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
@@ -935,8 +1168,16 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 else if constexpr (NORM == HIPETS_NORM_F32) x = (x - (float)sm.nmean[cc]) / (float)sm.nstd[cc];
                 v[q] = (c < md.in_dim && valid) ? x : 0.f;
             }
+            if constexpr (kB3) {  // three bf16 pieces per value, in the B-operand layout of wave_gemm_b3
+                u32x2 pc[3];
+                split3x4(f32x4{v[0], v[1], v[2], v[3]}, pc);
+                char* row = reinterpret_cast<char*>(sm.buf0) + (size_t)s * md.ld * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sm.buf0[s * md.ld + lds_col(4 * cq + q)] = v[q];
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(row + b3_offset(4 * cq, p)) = pc[p];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sm.buf0[s * md.ld + lds_col(4 * cq + q)] = v[q];
+            }
         }
     };
     auto build_input = [&](const int t) __attribute__((always_inline)) {
@@ -1008,6 +1249,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     mlp_layer_pre<R, S>(md, l + 1 == md.n_layers, cur_op, cur, nxt, wave, lane, prof, pre, nop);
                     cur_op = nop;
                     lds_barrier();
+                } else if constexpr (kB3) {
+                    mlp_layer_b3<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane);
+                    __syncthreads();
                 } else {
                     mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                     __syncthreads();

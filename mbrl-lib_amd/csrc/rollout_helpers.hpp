@@ -115,6 +115,38 @@ __global__ void pack_weights_kernel(float* dst, const float* src, const int* mem
     dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
 }
 
+// bf16x3 precision mode: the same weights as three bf16 pieces, one A-operand fragment of v_mfma_f32_16x16x32_bf16 per
+// (column tile c, 32-wide k chunk kk, piece p): dst unit (16 bytes) index ((c * KC32 + kk) * 3 + p) * 64 + lane holds
+// piece p of W[members[m]][32 kk + 8 (lane >> 4) + j][16 c + (lane & 15)], j = 0..7 (zero outside K x N; natural columns)
+__global__ void pack_weights_b3_kernel(uint4* dst, const float* src, const int* members, int M, int K, int N, int Kp32, int Np,
+                                       long long member_stride, long long layer_off, int src_nk) {
+    const int KC32 = Kp32 / 32, C = Np / 16;
+    const long long per_member = (long long)C * KC32 * 3 * 64;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_member * M) return;
+    const int m = (int)(i / per_member);
+    long long r = i % per_member;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int p = (int)(r % 3); r /= 3;
+    const int kk = (int)(r % KC32);
+    const int c = (int)(r / KC32);
+    const int n = 16 * c + (lane & 15);
+    unsigned w[4];
+    for (int jj = 0; jj < 4; ++jj) {
+        unsigned pair = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 32 * kk + 8 * (lane >> 4) + 2 * jj + h;
+            float v = 0.f;
+            if (k < K && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
+            unsigned pc[3];
+            split3(v, pc);
+            pair |= h ? pc[p] : (pc[p] >> 16);
+        }
+        w[jj] = pair;
+    }
+    dst[(size_t)m * member_stride + layer_off + (i % per_member)] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ void pack_bias_kernel(float* dst, const float* src, const int* members, int M, int N, int Np, int member_stride,
                                  int layer_off, int permute_cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

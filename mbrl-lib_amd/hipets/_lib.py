@@ -19,6 +19,7 @@ REW = {None: 0, "learned": 0, "cartpole": 1, "cartpole_pets": 2, "inverted_pendu
 TERM = {"no_termination": 0, "cartpole": 1, "inverted_pendulum": 2, "hopper": 3, "walker2d": 4, "ant": 5, "humanoid": 6}
 NORM = {"none": 0, "f32": 1, "f64": 2}
 ENSEMBLE = {"gaussian_mlp": 0, "basic_ensemble": 1}
+PREC = {"f32": 0, "bf16x3": 1}
 MODE_EXACT, MODE_FAST, MODE_DEVICE = 0, 1, 2
 MODES = {"exact": MODE_EXACT, "fast": MODE_FAST, "device": MODE_DEVICE}
 
@@ -36,6 +37,7 @@ class ModelDesc(C.Structure):
         ("min_logvar", C.POINTER(C.c_float)), ("max_logvar", C.POINTER(C.c_float)),
         ("weights", C.POINTER(C.c_void_p)), ("biases", C.POINTER(C.c_void_p)),
         ("ensemble_kind", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 

@@ -118,6 +118,7 @@ class Engine:
             d.normalizer = _lib.NORM["none"]
         basic = spec.ensemble_kind == "basic_ensemble"
         d.ensemble_kind = _lib.ENSEMBLE[spec.ensemble_kind]
+        d.precision = _lib.PREC[spec.precision]
         if not spec.deterministic:
             lo_t, hi_t = spec.min_logvar.detach().cpu().float(), spec.max_logvar.detach().cpu().float()
             if basic:  # every member owns its bounds: [M, out] (a shared [1, out] is broadcast)

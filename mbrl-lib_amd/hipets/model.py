@@ -54,6 +54,10 @@ class ModelSpec:
     #   independently from the generator (basic_ensemble.py:122-129, 255-260), any batch size, no elites,
     #   min/max_logvar are [E, out] (every member owns its bounds).
     ensemble_kind: str = "gaussian_mlp"
+    # arithmetic of the linear layers: "f32" (fp32 MFMA, the default and the graded mode) or "bf16x3" (fp32 operands as three
+    # bf16 pieces on the bf16 matrix pipe: fp32-accurate to a few product ulps, ~1.5x faster; available for the shapes that have
+    # a shape-specialised kernel instance -- anything else fails loudly at the rollout call)
+    precision: str = "f32"
 
     # ---- derived ---------------------------------------------------------------------------
     @property
@@ -84,6 +88,8 @@ class ModelSpec:
         return 2 * sum(int(w.shape[1]) * int(w.shape[2]) for w in self.weights)
 
     def validate(self):
+        if self.precision not in ("f32", "bf16x3"):
+            raise ValueError(f"precision must be 'f32' or 'bf16x3', got {self.precision!r}")
         if self.ensemble_kind not in ("gaussian_mlp", "basic_ensemble"):
             raise UnsupportedModelError(f"ensemble kind {self.ensemble_kind!r} has no fused implementation")
         if self.activation not in _ACT_BY_CLASS.values():

@@ -15,7 +15,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def to_spec(om, obs_dim, act_dim):
+def to_spec(om, obs_dim, act_dim, **kw):
     """OracleModel (test infra) -> hipets.ModelSpec (product).  The product never sees the oracle."""
     import hipets
 
@@ -24,7 +24,7 @@ def to_spec(om, obs_dim, act_dim):
         max_logvar=om.max_logvar, elite_models=om.elite_models, activation=om.activation, propagation=om.propagation,
         deterministic=om.deterministic, norm_mean=om.norm_mean, norm_std=om.norm_std, target_is_delta=om.target_is_delta,
         no_delta_list=om.no_delta_list, learned_rewards=om.learned_rewards, obs_process=om.obs_process, reward=om.reward,
-        termination=om.termination, ensemble_kind=om.ensemble_kind,
+        termination=om.termination, ensemble_kind=om.ensemble_kind, **kw,
     )
 
 
