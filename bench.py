@@ -41,7 +41,10 @@ POP, HORIZON, PARTICLES, ITERS, ELITE_RATIO, ALPHA = 500, 30, 20, 5, 0.1, 0.1
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
 
 
-def synthetic_spec(device):
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the sparsity headline is not used)
+
+
+def synthetic_spec(device, precision="f32"):
     """Random-init GaussianMLP ensemble with the reference initialiser (models/util.py:15-28: truncated
     normal std 1/(2 sqrt(in)), zero bias; logvar bounds -10 / 0.5), built on the product side (no oracle)."""
     import hipets
@@ -59,7 +62,7 @@ def synthetic_spec(device):
         weights=ws, biases=bs, obs_dim=OBS, act_dim=ACT, min_logvar=-10 * torch.ones(1, OBS), max_logvar=0.5 * torch.ones(1, OBS),
         activation="silu", propagation="random_model", norm_mean=torch.zeros(1, OBS + ACT, dtype=torch.float64),
         norm_std=torch.ones(1, OBS + ACT, dtype=torch.float64), target_is_delta=True, learned_rewards=False,
-        reward="halfcheetah", termination="no_termination")
+        reward="halfcheetah", termination="no_termination", precision=precision)
 
 
 def _usable_cores():
@@ -247,10 +250,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(mode, pop_total, steps, warmup):
+    def run(mode, pop_total, steps, warmup, spec_=None):
         """`warmup` untimed plans, then exactly `steps` plans between barrier + synchronize; MAX over ranks.
-        Returns (seconds, rollout-kernel launches, summed kernel ms)."""
-        eval_fn = hipets.make_eval_fn(spec, PARTICLES, engine=engine, seed=0, mode=mode)
+        Returns (seconds, rollout-kernel launches, summed kernel ms, steps per launch, event sampling stride)."""
+        eval_fn = hipets.make_eval_fn(spec_ if spec_ is not None else spec, PARTICLES, engine=engine, seed=0, mode=mode)
         opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop_total, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
         if sharded == "library":
             engine.set_plan_mode(mode)
@@ -329,6 +332,24 @@ def main():
         r2 = roofline_block(other, pop, l2, k2, spl2, stride2)
         extras[f"{other}_mode"] = {"workload": f"the same plan with mode='{other}' rollouts", "value": n_other * ITERS * pop * PARTICLES * HORIZON / e2,
                                    "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e2 / n_other, "roofline": r2}
+    if world == 1 and not args.no_extras:
+        # SEPARATELY reported arithmetic mode (the graded mode is fp32 MFMA): precision='bf16x3' -- fp32 operands as
+        # three bf16 pieces, six exact partial products per product on the bf16 matrix pipe, fp32 accumulate; its own parity
+        # evidence is tests/test_gpu_bf16x3.py (same oracle, same tolerances)
+        spec3 = synthetic_spec(device, precision="bf16x3")
+        blk = {"arithmetic": "fp32 operands split into 3 bf16 pieces, 6 v_mfma_f32_16x16x32_bf16 partial products per 16x16x32 block, fp32 accumulate",
+               "parity": "tests/test_gpu_bf16x3.py: T1 / T2 against the oracle at the fp32 mode's tolerances; <= 2e-5 relative to the fp32-MFMA kernel"}
+        for m in ("device", "fast"):
+            n3 = max(3, args.steps // 3)
+            e3_, l3, k3, spl3, stride3 = run(m, pop, n3, 2, spec_=spec3)
+            avg_s = (k3 / max(l3, 1)) * 1e-3
+            alg = flops_cs * pop * PARTICLES * spl3
+            blk[m] = {"value": n3 * ITERS * pop * PARTICLES * HORIZON / e3_, "unit": "candidate-steps/s", "ms_per_plan": 1e3 * e3_ / n3,
+                      "roofline": {"bound": "mfma", "achieved": 6 * alg / avg_s / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (bf16 MFMA issued: 6 x algorithmic)",
+                                   "frac": 6 * alg / avg_s / 1e12 / PEAK_BF16_TFLOPS, "avg_launch_ms": 1e3 * avg_s, "launches": l3,
+                                   "fp32_equivalent_tflops": alg / avg_s / 1e12, "fp32_equivalent_over_fp32_mfma_peak": alg / avg_s / 1e12 / PEAK_FP32_TFLOPS}}
+        extras["bf16x3_precision"] = blk
+        engine.set_model(spec)  # back to the graded arithmetic for the blocks below
     if world > 1 and not args.no_extras:
         alt_pop = POP if args.scaling == "weak" else POP * world
         n_alt = max(3, args.steps // 3)

@@ -1023,6 +1023,13 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         xs[q] = i < ROWS * NV ? i / NV : -1;
         xv[q] = i < ROWS * NV ? i - (i / NV) * NV : 0;
     }
+    if constexpr (kB3) {
+        // bf16x3: the k chunks are 32 wide, the column tiles 16: the last chunk of a 13-tile layer ends in 16 columns no epilogue
+        // ever writes.  Their weights are zero, but 0 x (whatever bits LDS holds) may be NaN: clear both activation buffers once.
+        f32x4* z = reinterpret_cast<f32x4*>(sm.buf0);
+        const int n16 = (int)(2 * align16((size_t)ROWS * md.ld * 4) / 16);
+        for (int i = tid; i < n16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
         // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
         const int nlv = deterministic ? 0 : lv_rows * md.out_dim;

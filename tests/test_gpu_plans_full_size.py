@@ -52,6 +52,7 @@ def replay_rollout(engine, om, s0, P, H, mode, seed):
 
 
 def check_values(dev_v, ref_v):
+    assert torch.isfinite(dev_v).all(), "non-finite values"
     tol = 1e-4 * torch.clamp(ref_v.abs(), min=1.0)
     bad = (dev_v - ref_v).abs() > tol
     assert not bad.any(), f"T2: max err {(dev_v - ref_v).abs().max():.3e}"

@@ -20,6 +20,7 @@ DEV = "cuda:0"
 
 def assert_returns_close(out, ref):
     out, ref = out.detach().cpu(), ref.detach().cpu()
+    assert torch.isfinite(out).all(), "non-finite returns"  # NaN compares false with everything: never let it pass the bound below
     tol = 1e-4 * torch.clamp(ref.abs(), min=1.0)
     bad = (out - ref).abs() > tol
     assert not bad.any(), f"max err {(out - ref).abs().max():.3e} at {int(bad.nonzero()[0])}"
