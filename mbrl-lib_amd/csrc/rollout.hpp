@@ -527,15 +527,25 @@ __host__ __device__ __forceinline__ void split3(float x, unsigned (&h)[3]) {
     const float r2 = r1 - bits_to_float(h[1]);
     h[2] = bf16_rne_bits(r2);
 }
-// four consecutive values -> per piece one 8-byte word pair (4 x bf16, little endian: value 0 in the low half of word 0)
+// four consecutive values -> per piece one 8-byte word pair (4 x bf16, little endian: value 0 in the low half of word 0).
+// v_cvt_pk_bf16_f32 rounds two floats to nearest-even and packs them in exactly that order: one conversion, two bit
+// operations and one packed subtract per pair and piece (the host-side split3 above states the same arithmetic bit by bit).
 __device__ __forceinline__ void split3x4(const f32x4 v, u32x2 (&out)[3]) {
-    unsigned h[4][3];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split3(v[i], h[i]);
+    using f32p = __attribute__((ext_vector_type(2))) float;
+    using bf16p = __attribute__((ext_vector_type(2))) __bf16;
+    f32p lo = {v[0], v[1]}, hi = {v[2], v[3]};
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        out[p][0] = (h[0][p] >> 16) | h[1][p];
-        out[p][1] = (h[2][p] >> 16) | h[3][p];
+        const bf16p hl = __builtin_convertvector(lo, bf16p), hh = __builtin_convertvector(hi, bf16p);
+        unsigned ul, uh;
+        __builtin_memcpy(&ul, &hl, 4);
+        __builtin_memcpy(&uh, &hh, 4);
+        out[p][0] = ul;
+        out[p][1] = uh;
+        if (p < 2) {
+            lo = lo - f32p{bits_to_float(ul << 16), bits_to_float(ul & 0xFFFF0000u)};
+            hi = hi - f32p{bits_to_float(uh << 16), bits_to_float(uh & 0xFFFF0000u)};
+        }
     }
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) {
@@ -982,7 +992,15 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fast = S::KMODE >= 0 ? S::KMODE == HIPETS_MODE_FAST : ra.mode == HIPETS_MODE_FAST;
     const bool expectation = kLean ? false : md.propagation == HIPETS_PROP_EXPECTATION;
-    const int wg = blockIdx.x;
+    // Modes whose workgroups are bound to a member (EXACT / DEVICE: member = wg / groups): hardware deals block b to XCD b % 8
+    // (observed, used for speed only), so the logical workgroup index is taken XCD-major -- XCD x runs a CONTIGUOUS range of
+    // logical workgroups, i.e. the workgroups of at most two members, and its 4 MiB L2 streams two members' weights instead of
+    // all of them (bf16x3: 0.83 MB per member, all five = 4.2 MB do not fit one L2).  Any bijection is correct.
+    int wg = blockIdx.x;
+    if (!fast) {
+        const int nwg = gridDim.x, x = wg & 7, slot = wg >> 3;
+        wg = x * (nwg >> 3) + min(x, nwg & 7) + slot;
+    }
 
     // ---- which rollout rows does this workgroup own; per-dimension constants into LDS -------------
     int domain = 0;
