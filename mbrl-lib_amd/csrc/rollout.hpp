@@ -893,6 +893,7 @@ struct RolloutSmem {
     float* lrew;     // [ROWS] learned reward of the current step
     int* term;       // [ROWS]
     int* rowid;      // [ROWS] global row id (candidate*P + particle) or -1
+    int* pend;       // [2][ROWS] persistent DEVICE form: running total / flag granule of the row not yet collected
     double* nmean;   // [in_dim] normaliser stats (f64 like the reference)
     double* nstd;    // [in_dim] (f64 normaliser: holds 1 / std)
     float* minlv;    // [lv_rows][out_dim]
@@ -912,7 +913,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += 2 * align16((size_t)rows * ld * 4);
     n += align16((size_t)rows * obs_dim * 4);
     n += align16((size_t)2 * rows * act_dim * 4);
-    n += 4 * align16((size_t)rows * 4);
+    n += 4 * align16((size_t)rows * 4) + align16((size_t)2 * rows * 4);
     n += 2 * align16((size_t)in_dim * 8);
     n += 2 * align16((size_t)lv_rows * out_dim * 4);
     n += align16((size_t)obs_dim * 4);
@@ -977,6 +978,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         sm.lrew = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * 4);
         sm.term = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
         sm.rowid = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
+        sm.pend = reinterpret_cast<int*>(p); p += align16((size_t)2 * ROWS * 4);
         sm.nmean = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
         sm.nstd = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
         sm.minlv = reinterpret_cast<float*>(p); p += align16((size_t)md.lv_rows * md.out_dim * 4);
@@ -1105,6 +1107,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             sm.tot[s] = (!fast && !persist && rid >= 0) ? ra.totals[rid] : 0.f;
             sm.term[s] = (!fast && !persist && rid >= 0) ? (int)ra.term[rid] : 0;
             sm.lrew[s] = 0.f;
+            sm.pend[s] = 0;
+            sm.pend[ROWS + s] = 0;
         }
     };
 
@@ -1306,6 +1310,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
         // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
         // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
+        unsigned long long* const handover = (more && persist) ? ra.exchange : nullptr;
+        const unsigned long long handover_tag = (unsigned long long)(t + 1) << 32;
         auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
             constexpr bool EXPECT = decltype(expect_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
@@ -1354,6 +1360,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     if (d < md.obs_dim) {
                         const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
                         sm.state[s * md.obs_dim + d] = nobs;
+                        // persistent DEVICE form: the row's next owner waits for this value -- on its way before the reward phase
+                        if (handover) __hip_atomic_store(handover + (size_t)rid * NV + d, handover_tag | __float_as_uint(nobs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1, 8 B
                         if (trace_next_obs) trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
                     } else if (d < md.out_dim) {
                         sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
@@ -1382,59 +1390,78 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 
         // ---- reward, termination, masked accumulation (model_env.py:124-129, :186-188) of step t, and, in the
         // same barrier interval, the model input of step t+1 (both only READ the new state) ------------------
+        // Persistent DEVICE form: every row changes workgroups now.  Its new state left in the sampling phase; its running
+        // total and flag follow from here, and the same thread then evaluates which row the slot holds in step t + 1.
         for (int s = tid; s < ROWS; s += kThreads) {
             const int rid = sm.rowid[s];
-            if (rid < 0) continue;
-            const float* st = sm.state + s * md.obs_dim;
-            const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
-            float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
-            const bool done = term_eval(st, md.obs_dim, term_fn);
-            if (trace_rewards) trace_rewards[(size_t)t * ra.B + rid] = r;
-            if (sm.term[s]) r = 0.f;
-            sm.term[s] = sm.term[s] | (done ? 1 : 0);
-            sm.tot[s] += r;
+            if (rid >= 0) {
+                const float* st = sm.state + s * md.obs_dim;
+                const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
+                float tot = sm.tot[s];
+                int trm = sm.term[s];
+                if (persist) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
+                    unsigned long long* const src = ra.exchange + (size_t)rid * NV + md.obs_dim;
+                    const unsigned long long want = (unsigned long long)t;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (!sm.pend[k * ROWS + s]) continue;
+                        sm.pend[k * ROWS + s] = 0;
+                        const long long t_poll = wall_clock64();
+                        unsigned long long g = 0;
+                        for (int spins = 0;; ++spins) {
+                            g = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((g >> 32) == want) break;
+                            if ((spins & 63) == 63 && wall_clock64() - t_poll > 20000000ll) {
+                                *ra.error_flag = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (k == 0) tot = __uint_as_float((unsigned)g);
+                        else trm = (int)(unsigned)g;
+                    }
+                }
+                float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
+                const bool done = term_eval(st, md.obs_dim, term_fn);
+                if (trace_rewards) trace_rewards[(size_t)t * ra.B + rid] = r;
+                if (trm) r = 0.f;
+                trm = trm | (done ? 1 : 0);
+                tot += r;
+                sm.term[s] = trm;
+                sm.tot[s] = tot;
+                if (handover) {
+                    __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim, handover_tag | __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim + 1, handover_tag | (unsigned)trm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (handover) {  // the slot's row of step t + 1 (only this thread reads rowid[s] between the two barriers around here)
+                const int j = (wg % ra.groups) * ROWS + s;
+                sm.rowid[s] = j < ra.rows_per_domain
+                                  ? (int)perm_apply((unsigned)(domain * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t + 1]) : -1;
+                sm.lrew[s] = 0.f;
+            }
         }
         if (more && !persist) build_input(t + 1);
         __syncthreads();
         prof.mark(10);
 
         if (more && persist) {
-            // ---- hand the rows over: publish what this workgroup computed, become the owner of other rows, collect them ----
-            const unsigned long long tag = (unsigned long long)(t + 1) << 32;
-            auto publish_item = [&](const int s, const int v) __attribute__((always_inline)) {
-                const int rid = sm.rowid[s];
-                if (rid < 0) return;
-                const unsigned bits = v < md.obs_dim ? __float_as_uint(sm.state[s * md.obs_dim + v])
-                                                     : (v == md.obs_dim ? __float_as_uint(sm.tot[s]) : (unsigned)sm.term[s]);
-                __hip_atomic_store(ra.exchange + (size_t)rid * NV + v, tag | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1, 8 B
-            };
-#pragma unroll
-            for (int q = 0; q < kG; ++q)
-                if (xs[q] >= 0) publish_item(xs[q], xv[q]);
-            for (int i = tid + kG * kThreads; i < ROWS * NV; i += kThreads) publish_item(i / NV, i - (i / NV) * NV);  // very wide states
-            __syncthreads();  // everyone has read rowid / state / tot / term of the old rows
-            {
-                const int j0 = (wg % ra.groups) * ROWS;
-                const PermKeys keys = ra.step_keys[t + 1];
-                for (int s = tid; s < ROWS; s += kThreads) {
-                    const int j = j0 + s;
-                    sm.rowid[s] = j < ra.rows_per_domain
-                                      ? (int)perm_apply((unsigned)(domain * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, keys) : -1;
-                }
-            }
-            __syncthreads();
+            // ---- collect the rows this workgroup owns in step t + 1: 8-byte {value bits, step tag} granules, self-validating ----
             compute_act_base();
             float av2[kPrefetch];
             fetch_actions_issue(t + 1, av2);  // in flight while the rows arrive
+            const unsigned long long tag = handover_tag;
             for (int base = 0; base < ROWS * NV; base += kG * kThreads) {
                 const unsigned long long* src[kG];
                 unsigned long long g[kG];
                 int gs[kG], gv[kG];
+                bool soft[kG];  // running total / flag: wanted at the NEXT reward phase only -- one look now, the rest there
 #pragma unroll
                 for (int q = 0; q < kG; ++q) {
                     const int i = base + tid + q * kThreads;
                     gs[q] = base == 0 ? xs[q] : (i < ROWS * NV ? i / NV : -1);
                     gv[q] = base == 0 ? xv[q] : (i < ROWS * NV ? i - (i / NV) * NV : 0);
+                    soft[q] = gv[q] >= md.obs_dim;
                     src[q] = nullptr;
                     g[q] = tag;  // rows of the padding: zero state, total, flag
                     if (gs[q] >= 0) {
@@ -1450,7 +1477,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                         if (src[q]) {
                             g[q] = __hip_atomic_load(src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1 line
                             if ((g[q] >> 32) == (unsigned long long)(t + 1)) src[q] = nullptr;
-                            else ready = false;
+                            else if (!soft[q]) ready = false;
                         }
                     if (ready) break;
                     // a hand-over takes microseconds; 0.2 s without the producer means it is not running at all (the grid is not
@@ -1466,11 +1493,11 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     if (gs[q] >= 0) {
                         const unsigned bits = (unsigned)g[q];
                         if (gv[q] < md.obs_dim) sm.state[gs[q] * md.obs_dim + gv[q]] = __uint_as_float(bits);
+                        else if (src[q]) sm.pend[(gv[q] - md.obs_dim) * ROWS + gs[q]] = 1;  // not there yet: the reward phase fetches it
                         else if (gv[q] == md.obs_dim) sm.tot[gs[q]] = __uint_as_float(bits);
                         else sm.term[gs[q]] = (int)bits;
                     }
             }
-            for (int s = tid; s < ROWS; s += kThreads) sm.lrew[s] = 0.f;
             fetch_actions_commit(t + 1, av2);
             __syncthreads();
             build_input(t + 1);
