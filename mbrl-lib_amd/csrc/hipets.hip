@@ -78,7 +78,11 @@ struct hipets_engine {
     // rollout workspace
     DevBuf s0, state, totals, term, schedule, plan_schedule;
     // DEVICE mode, persistent form: row exchange table, per-step permutation keys, timeout flag (host-mapped)
-    DevBuf exchange, step_keys;
+    DevBuf exchange, step_keys, plan_keys;
+    uint32_t tag_base = 0;  // hand-over tags handed out so far (exchange granules hold tags <= tag_base)
+    // the key tables a fused plan generated up front: rollouts (plan_keys_seed, stream in [first, first + count), H) read them
+    uint64_t plan_keys_seed = 0, plan_keys_first = 0;
+    int plan_keys_count = 0, plan_keys_H = 0;
     int* error_flag = nullptr;
     bool persistent_ok = true;
     // plan workspace
@@ -180,6 +184,15 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
     *sched = nullptr;
     *sched_stride = 0;
+    if (md.propagation == HIPETS_PROP_RANDOM_MODEL && iters >= 1 && e->plan_mode == HIPETS_MODE_DEVICE && e->persistent_ok) {
+        // the per-step permutation keys of every rollout of the plan in one launch (rollout_impl finds them by seed / stream id)
+        if (e->plan_keys.ensure((size_t)iters * H * sizeof(PermKeys))) return 1;
+        hipLaunchKernelGGL(step_keys_kernel, dim3((H + 63) / 64, iters), dim3(64), 0, st, e->plan_keys.as<PermKeys>(), H, (unsigned long long)seed,
+                           (unsigned long long)first_stream);
+        HCHECK(hipGetLastError());
+        e->plan_keys_seed = seed; e->plan_keys_first = first_stream; e->plan_keys_count = iters; e->plan_keys_H = H;
+        return 0;
+    }
     if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
     const long long tiles = (pop + kTile - 1) / kTile;
     const int R = choose_R(e, tiles, P, 0, H);
@@ -332,7 +345,7 @@ void hipets_destroy(hipets_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
     for (DevBuf* b : {&e->w3pack, &e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
-                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->mu, &e->disp, &e->population, &e->values,
+                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->plan_keys, &e->mu, &e->disp, &e->population, &e->values,
                       &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -589,11 +602,20 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         const size_t lds = lds_for(e, R, H);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
+        // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
+        // (state through HBM); TS-infinity / expectation rollouts of DEVICE mode keep their rows and run as ONE launch
+        const bool per_step = !device || md.propagation == HIPETS_PROP_RANDOM_MODEL;
+        // DEVICE + random_model with every workgroup resident at once (one workgroup always fits a CU, so <= #CUs workgroups
+        // are): ONE launch for the horizon, rows handed over between workgroups through the tagged-granule table.  Larger
+        // batches (cfg4, cfg5: one step is >= 100 us of work) keep one launch per step.
+        const bool persistent = device && per_step && e->persistent_ok && domains * groups <= e->num_cu && H > 1;
         if (e->state.ensure((size_t)B * md.obs_dim * 4) || e->term.ensure((size_t)B)) return 1;
-        hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
-                           e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
-                           md.obs_dim);
-        HCHECK(hipGetLastError());
+        if (!persistent) {  // the persistent form starts from s0 itself and writes every row's total at the end
+            hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
+                               e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
+                               md.obs_dim);
+            HCHECK(hipGetLastError());
+        }
         ra.groups = groups;
         ra.rows_per_domain = rpd;
         ra.state = e->state.as<float>();
@@ -613,22 +635,30 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             ra.eps = o->eps;
             ra.use_philox = 0;
         }
-        // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
-        // (state through HBM); TS-infinity / expectation rollouts of DEVICE mode keep their rows and run as ONE launch
-        const bool per_step = !device || md.propagation == HIPETS_PROP_RANDOM_MODEL;
-        // DEVICE + random_model with every workgroup resident at once (one workgroup always fits a CU, so <= #CUs workgroups
-        // are): ONE launch for the horizon, rows handed over between workgroups through the tagged-granule table.  Larger
-        // batches (cfg4, cfg5: one step is >= 100 us of work) keep one launch per step.
-        const bool persistent = device && per_step && e->persistent_ok && domains * groups <= e->num_cu && H > 1;
         if (persistent) {
             const size_t nv = (size_t)md.obs_dim + 2;
-            if (e->exchange.ensure((size_t)B * nv * 8) || e->step_keys.ensure((size_t)H * sizeof(PermKeys))) return 1;
-            HCHECK(hipMemsetAsync(e->exchange.p, 0, (size_t)B * nv * 8, st));  // tag 0: no step's data
-            hipLaunchKernelGGL(step_keys_kernel, dim3((H + 63) / 64), dim3(64), 0, st, e->step_keys.as<PermKeys>(), H, (unsigned long long)o->seed,
-                               (unsigned long long)o->stream_id);
-            HCHECK(hipGetLastError());
+            const size_t cap_before = e->exchange.cap;
+            if (e->exchange.ensure((size_t)B * nv * 8)) return 1;
+            // hand-over tags grow monotonically across launches (step t of this launch: tag_base + t + 1), so a granule left by an
+            // earlier rollout can never pass for this one's: the table is cleared only when it is new or the 32-bit tag would wrap
+            if (e->exchange.cap != cap_before || e->tag_base > 0xFFFFFFFFu - 2u * (uint32_t)H - 2u) {
+                HCHECK(hipMemsetAsync(e->exchange.p, 0, e->exchange.cap, st));
+                e->tag_base = 0;
+            }
+            ra.tag_base = e->tag_base;
+            e->tag_base += (uint32_t)H;
             ra.exchange = e->exchange.as<unsigned long long>();
-            ra.step_keys = e->step_keys.as<PermKeys>();
+            const uint64_t sid = o->stream_id;
+            if (e->plan_keys.p && o->seed == e->plan_keys_seed && H == e->plan_keys_H && sid >= e->plan_keys_first &&
+                sid - e->plan_keys_first < (uint64_t)e->plan_keys_count) {
+                ra.step_keys = e->plan_keys.as<PermKeys>() + (size_t)(sid - e->plan_keys_first) * H;  // generated by the plan's prologue
+            } else {
+                if (e->step_keys.ensure((size_t)H * sizeof(PermKeys))) return 1;
+                hipLaunchKernelGGL(step_keys_kernel, dim3((H + 63) / 64), dim3(64), 0, st, e->step_keys.as<PermKeys>(), H, (unsigned long long)o->seed,
+                                   (unsigned long long)o->stream_id);
+                HCHECK(hipGetLastError());
+                ra.step_keys = e->step_keys.as<PermKeys>();
+            }
             ra.error_flag = e->error_flag;
             ra.t_begin = 0;
             ra.t_end = H;

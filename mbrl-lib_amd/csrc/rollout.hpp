@@ -99,6 +99,7 @@ struct RolloutArgs {
     // terminated flag).  A granule is written by ONE write-through (sc1) 8-byte store and polled with sc1 loads until its
     // tag is the awaited step: self-validating, so no fence, flag or grid barrier is involved (MI355X_MICROARCH.md R2).
     unsigned long long* exchange;  // null: per-step launches
+    unsigned tag_base;             // step t's hand-over carries tag tag_base + t + 1 (the engine advances it by H per launch: no clearing)
     const PermKeys* step_keys;     // DEVICE [H]: round keys of every step's permutation
     int* error_flag;               // set to 1 when a poll exceeds its spin bound (another workgroup was not resident)
 };
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
         // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
         unsigned long long* const handover = (more && persist) ? ra.exchange : nullptr;
-        const unsigned long long handover_tag = (unsigned long long)(t + 1) << 32;
+        const unsigned long long handover_tag = (unsigned long long)(ra.tag_base + (unsigned)t + 1u) << 32;  // tags never repeat across launches
         auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
             constexpr bool EXPECT = decltype(expect_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
@@ -1401,7 +1402,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 int trm = sm.term[s];
                 if (persist) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
                     unsigned long long* const src = ra.exchange + (size_t)rid * NV + md.obs_dim;
-                    const unsigned long long want = (unsigned long long)t;
+                    const unsigned long long want = (unsigned long long)(ra.tag_base + (unsigned)t);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         if (!sm.pend[k * ROWS + s]) continue;
@@ -1476,7 +1477,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     for (int q = 0; q < kG; ++q)
                         if (src[q]) {
                             g[q] = __hip_atomic_load(src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1 line
-                            if ((g[q] >> 32) == (unsigned long long)(t + 1)) src[q] = nullptr;
+                            if ((g[q] >> 32) == (tag >> 32)) src[q] = nullptr;
                             else if (!soft[q]) ready = false;
                         }
                     if (ready) break;

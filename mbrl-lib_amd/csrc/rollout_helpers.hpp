@@ -85,9 +85,10 @@ __global__ void export_perms_kernel(long long* out, int H, unsigned n, unsigned 
 }
 
 // round keys of the H per-step permutations of a DEVICE-mode rollout (persistent form reads them from memory)
+// blockIdx.y: consecutive rollouts of one plan (stream ids stream_id, stream_id + 1, ...), key tables back to back
 __global__ void step_keys_kernel(PermKeys* keys, int H, unsigned long long seed, unsigned long long stream_id) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < H) keys[t] = perm_round_keys(perm_key(seed, stream_id, (unsigned)t));
+    if (t < H) keys[(size_t)blockIdx.y * H + t] = perm_round_keys(perm_key(seed, stream_id + blockIdx.y, (unsigned)t));
 }
 
 // Re-pack [E, K, N] row-major weights of the active members into MFMA B-fragment order:
