@@ -1051,19 +1051,22 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         const int n16 = (int)(2 * align16((size_t)ROWS * md.ld * 4) / 16);
         for (int i = tid; i < n16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    {   // per-dimension constants -> LDS.  All loads of a thread are issued before the first store, so the tables arrive in ONE
-        // global round trip (element i of every table is fetched by thread i; tables longer than the workgroup loop on)
-        const int nlv = deterministic ? 0 : lv_rows * md.out_dim;
-        const bool norm = normalizer != HIPETS_NORM_NONE;
-        double c_nm = 0.0, c_ns = 1.0;
-        float c_lo = 0.f, c_hi = 0.f;
-        int c_nd = 0, c_lm = 0;
-        constexpr int kMetaWords = (int)(sizeof(LayerMeta) / sizeof(int));  // the layer table travels as plain 32-bit words
-        const int n_meta = md.n_layers * kMetaWords;                        // (<= 48: one word per thread, no private copy)
-        if (norm && tid < md.in_dim) { c_nm = md.norm_mean[tid]; c_ns = md.norm_std[tid]; }
-        if (tid < nlv) { c_lo = md.min_lv[tid]; c_hi = md.max_lv[tid]; }
-        if (tid < md.obs_dim) c_nd = md.no_delta[tid];
-        if (tid < n_meta) c_lm = reinterpret_cast<const int*>(md.layers)[tid];
+    // ---- per-dimension constants -> LDS, and the rows' initial state / totals / flags / first actions: EVERY global load of the
+    // prologue is issued before the first dependent LDS store, so the whole prologue costs ONE global round trip (the per-step
+    // launches of EXACT / DEVICE mode pay it once per step and workgroup; element i of every table is fetched by thread i,
+    // tables longer than the workgroup loop on afterwards)
+    const int nlv = deterministic ? 0 : lv_rows * md.out_dim;
+    const bool norm = normalizer != HIPETS_NORM_NONE;
+    double c_nm = 0.0, c_ns = 1.0;
+    float c_lo = 0.f, c_hi = 0.f;
+    int c_nd = 0, c_lm = 0;
+    constexpr int kMetaWords = (int)(sizeof(LayerMeta) / sizeof(int));  // the layer table travels as plain 32-bit words
+    const int n_meta = md.n_layers * kMetaWords;                        // (<= 48: one word per thread, no private copy)
+    if (norm && tid < md.in_dim) { c_nm = md.norm_mean[tid]; c_ns = md.norm_std[tid]; }
+    if (tid < nlv) { c_lo = md.min_lv[tid]; c_hi = md.max_lv[tid]; }
+    if (tid < md.obs_dim) c_nd = md.no_delta[tid];
+    if (tid < n_meta) c_lm = reinterpret_cast<const int*>(md.layers)[tid];
+    auto commit_constants = [&]() __attribute__((always_inline)) {
         if (norm && tid < md.in_dim) { sm.nmean[tid] = c_nm; sm.nstd[tid] = normalizer == HIPETS_NORM_F64 ? 1.0 / c_ns : c_ns; }  // f64: 1 / std, see build_input
         if (tid < nlv) { sm.minlv[tid] = c_lo; sm.maxlv[tid] = c_hi; }
         if (tid < md.obs_dim) sm.nodelta[tid] = c_nd;
@@ -1072,14 +1075,25 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             for (int i = tid + kThreads; i < md.in_dim; i += kThreads) { sm.nmean[i] = md.norm_mean[i]; sm.nstd[i] = normalizer == HIPETS_NORM_F64 ? 1.0 / md.norm_std[i] : md.norm_std[i]; }
         for (int i = tid + kThreads; i < nlv; i += kThreads) { sm.minlv[i] = md.min_lv[i]; sm.maxlv[i] = md.max_lv[i]; }
         for (int i = tid + kThreads; i < md.obs_dim; i += kThreads) sm.nodelta[i] = md.no_delta[i];
-    }
-    __syncthreads();
+    };
+    lds_barrier();  // sm.rowid (and the B3 clear) visible; the constants' loads stay in flight
 
     // ---- initial state, totals, flags: loads issued in batches of kStage per thread (one round trip, not one per element) ----
     auto load_initial_state = [&]() __attribute__((always_inline)) {
         constexpr int kStage = 4;
+        constexpr int kRowStage = (ROWS + kThreads - 1) / kThreads;
         const int n_st = ROWS * md.obs_dim;
-        for (int base = tid; base < n_st; base += kStage * kThreads) {
+        float tot0[kRowStage];
+        int term0[kRowStage];
+#pragma unroll
+        for (int q = 0; q < kRowStage; ++q) {
+            const int s = tid + q * kThreads;
+            const int rid = s < ROWS ? sm.rowid[s] : -1;
+            tot0[q] = (!fast && !persist && rid >= 0) ? ra.totals[rid] : 0.f;
+            term0[q] = (!fast && !persist && rid >= 0) ? (int)ra.term[rid] : 0;
+        }
+        bool first = true;
+        for (int base = tid; base < n_st || first; base += kStage * kThreads) {
             float v[kStage];
 #pragma unroll
             for (int q = 0; q < kStage; ++q) {
@@ -1097,19 +1111,26 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     }
                 }
             }
+            if (first) {  // everything the prologue needs from global memory has been requested: now the dependent stores
+                commit_constants();
+#pragma unroll
+                for (int q = 0; q < kRowStage; ++q) {
+                    const int s = tid + q * kThreads;
+                    if (s < ROWS) {
+                        sm.tot[s] = tot0[q];
+                        sm.term[s] = term0[q];
+                        sm.lrew[s] = 0.f;
+                        sm.pend[s] = 0;
+                        sm.pend[ROWS + s] = 0;
+                    }
+                }
+                first = false;
+            }
 #pragma unroll
             for (int q = 0; q < kStage; ++q) {
                 const int i = base + q * kThreads;
                 if (i < n_st) sm.state[i] = v[q];
             }
-        }
-        for (int s = tid; s < ROWS; s += kThreads) {
-            const int rid = sm.rowid[s];
-            sm.tot[s] = (!fast && !persist && rid >= 0) ? ra.totals[rid] : 0.f;
-            sm.term[s] = (!fast && !persist && rid >= 0) ? (int)ra.term[rid] : 0;
-            sm.lrew[s] = 0.f;
-            sm.pend[s] = 0;
-            sm.pend[ROWS + s] = 0;
         }
     };
 
@@ -1168,7 +1189,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 
     // model input of step t: cat(obs_process(obs), act), normalised (one_dim_tr_model.py:103-116), into buf0.
     // One item = (row, 4 consecutive columns): four independent LDS-read -> f64 normalise -> LDS-write chains.
-    const int kq = (kB3 ? sm.lmeta[0].Kp32 : Kp0) >> 2;  // column quads per row (the padded input width is a multiple of 16 / 32)
+    int kq = Kp0 >> 2;  // column quads per row (the padded input width is a multiple of 16; bf16x3: of 32, set once the layer table is in LDS)
     // The (wave-uniform) normaliser / obs-preprocess switches are resolved ONCE per call into a compile-time variant:
     // with the switches inside, each of the four elements became its own chain of scalar branches and waits.
     auto build_input_impl = [&](const int t, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
@@ -1230,14 +1251,6 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     };
 
-    Pre pre;      // chunk-0 weight fragments + biases of the NEXT linear op of this wave (kPre kernels)
-    NextOp cur_op;  // ... and that op's descriptor
-    cur_op.valid = false;
-    if constexpr (kPre) {
-        const int m0 = fast ? __builtin_amdgcn_readfirstlane(sm.sched[ra.t_begin]) : domain;
-        cur_op = describe_layer<R, S>(md, sm.lmeta, 0, m0, wave);
-        prefetch_issue(cur_op, lane, pre);
-    }
     {   // the first step's actions are in flight while the state / totals / flags are fetched: one round trip for all of it
         // (the per-step launches of EXACT / DEVICE mode pay this prologue every step)
         float av[kPrefetch];
@@ -1246,6 +1259,15 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         fetch_actions_commit(ra.t_begin, av);
     }
     __syncthreads();
+    if constexpr (kB3) kq = sm.lmeta[0].Kp32 >> 2;
+    Pre pre;      // chunk-0 weight fragments + biases of the NEXT linear op of this wave (kPre kernels)
+    NextOp cur_op;  // ... and that op's descriptor
+    cur_op.valid = false;
+    if constexpr (kPre) {
+        const int m0 = fast ? __builtin_amdgcn_readfirstlane(sm.sched[ra.t_begin]) : domain;
+        cur_op = describe_layer<R, S>(md, sm.lmeta, 0, m0, wave);
+        prefetch_issue(cur_op, lane, pre);
+    }
     build_input(ra.t_begin);
     __syncthreads();
     prof.mark(0);
