@@ -111,7 +111,7 @@ namespace {
 
 int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutArgs& ra, hipStream_t st) {
     hipEvent_t a = nullptr, b = nullptr;
-    const bool timed = e->timing && (e->launch_counter++ % (unsigned long long)e->timing_stride) == 0;
+    const bool timed = !ra.capacity_out && e->timing && (e->launch_counter++ % (unsigned long long)e->timing_stride) == 0;
     if (timed) {
         if (!e->event_pool.empty()) {
             a = e->event_pool.back().first;
@@ -605,17 +605,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
         // (state through HBM); TS-infinity / expectation rollouts of DEVICE mode keep their rows and run as ONE launch
         const bool per_step = !device || md.propagation == HIPETS_PROP_RANDOM_MODEL;
-        // DEVICE + random_model with every workgroup resident at once (one workgroup always fits a CU, so <= #CUs workgroups
-        // are): ONE launch for the horizon, rows handed over between workgroups through the tagged-granule table.  Larger
-        // batches (cfg4, cfg5: one step is >= 100 us of work) keep one launch per step.
-        const bool persistent = device && per_step && e->persistent_ok && domains * groups <= e->num_cu && H > 1;
         if (e->state.ensure((size_t)B * md.obs_dim * 4) || e->term.ensure((size_t)B)) return 1;
-        if (!persistent) {  // the persistent form starts from s0 itself and writes every row's total at the end
-            hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
-                               e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
-                               md.obs_dim);
-            HCHECK(hipGetLastError());
-        }
         ra.groups = groups;
         ra.rows_per_domain = rpd;
         ra.state = e->state.as<float>();
@@ -634,6 +624,27 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             ra.perm_step = md.propagation == HIPETS_PROP_RANDOM_MODEL ? (long long)domains * rpd : 0;
             ra.eps = o->eps;
             ra.use_philox = 0;
+        }
+        // DEVICE + random_model: ONE launch for the horizon, rows handed over between workgroups through the tagged-granule
+        // table.  Only as many workgroups as are resident at once are launched; a batch with more logical workgroups (cfg4: 435)
+        // is served in turns, workgroup b taking b, b + grid, ... every step.
+        bool persistent = device && per_step && e->persistent_ok && H > 1;
+        if (persistent && domains * groups > e->num_cu) {
+            // Turns pay off when a CU holds ONE workgroup of this instance (cfg4: 4.51 -> 4.11 ms per rollout, cfg4' 16.4 -> 15.0).
+            // Where two are resident, one launch per step lets the hardware deal 1 250 workgroups to 512 slots as they free up;
+            // fixed turns (3 for some workgroups, 2 for the rest) measured slower there (cfg5: 7.3 vs 6.6 ms).
+            int capacity = 0;
+            RolloutArgs q = ra;
+            q.exchange = reinterpret_cast<unsigned long long*>(&capacity);  // marks the persistent form for the launcher; never dereferenced
+            q.capacity_out = &capacity;
+            if (launch_rollout(e, R, domains * groups, lds, q, st)) return 1;
+            persistent = domains * groups <= capacity || capacity <= e->num_cu;
+        }
+        if (!persistent) {  // the persistent form starts from s0 itself and writes every row's total at the end
+            hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
+                               e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
+                               md.obs_dim);
+            HCHECK(hipGetLastError());
         }
         if (persistent) {
             const size_t nv = (size_t)md.obs_dim + 2;
@@ -662,7 +673,8 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             ra.error_flag = e->error_flag;
             ra.t_begin = 0;
             ra.t_end = H;
-            if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
+            ra.n_logical = domains * groups;
+            if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;  // cut to the resident capacity by the launcher
         } else if (per_step) {
             for (int t = 0; t < H; ++t) {
                 ra.t_begin = t;

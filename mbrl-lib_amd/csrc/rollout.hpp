@@ -100,6 +100,9 @@ struct RolloutArgs {
     // tag is the awaited step: self-validating, so no fence, flag or grid barrier is involved (MI355X_MICROARCH.md R2).
     unsigned long long* exchange;  // null: per-step launches
     unsigned tag_base;             // step t's hand-over carries tag tag_base + t + 1 (the engine advances it by H per launch: no clearing)
+    int* capacity_out;             // HOST pointer, launcher only: when set, no launch -- the resident capacity (workgroups) is stored here
+    int n_logical;                 // persistent form: logical workgroups (member domain x row group); a launched workgroup serves the
+                                   // logical ones wg, wg + gridDim.x, ... one after the other within every step (batches larger than the chip)
     const PermKeys* step_keys;     // DEVICE [H]: round keys of every step's permutation
     int* error_flag;               // set to 1 when a poll exceeds its spin bound (another workgroup was not resident)
 };
@@ -1272,8 +1275,18 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     __syncthreads();
     prof.mark(0);
 
-    for (int t = ra.t_begin; t < ra.t_end; ++t) {
+    // Persistent DEVICE form with more logical workgroups than launched ones: within every step this workgroup serves its
+    // logical workgroups in turn (sequence index q = step * n_serve + turn); each turn collects its rows from the hand-over
+    // table, runs the step, publishes.  Only a step's first turn can find rows missing (published by other workgroups' last
+    // turns of the previous step); the later turns' rows arrived while the earlier ones computed.
+    const int n_serve = persist ? (ra.n_logical - wg + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int n_seq = (ra.t_end - ra.t_begin) * n_serve;
+    for (int q_seq = 0; q_seq < n_seq; ++q_seq) {
+        const int t = ra.t_begin + q_seq / n_serve;
         const bool more = t + 1 < ra.t_end;
+        const bool has_next = q_seq + 1 < n_seq;  // persistent form: another (step, turn) follows
+        const int t_next = ra.t_begin + (q_seq + 1) / n_serve;
+        const int v_next = wg + ((q_seq + 1) - ((q_seq + 1) / n_serve) * n_serve) * (int)gridDim.x;  // its logical workgroup
         float av[kPrefetch];
         if (more && !persist) fetch_actions_issue(t + 1, av);  // consumed after the sampling phase: the HBM / L2 latency hides behind the MLP
         const int n_run = expectation ? md.M : 1;
@@ -1455,12 +1468,14 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 if (handover) {
                     __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim, handover_tag | __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim + 1, handover_tag | (unsigned)trm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (persist) {
+                    ra.totals[rid] = tot;  // last step: the row's return
                 }
             }
-            if (handover) {  // the slot's row of step t + 1 (only this thread reads rowid[s] between the two barriers around here)
-                const int j = (wg % ra.groups) * ROWS + s;
+            if (persist && has_next) {  // the slot's row in the next turn (only this thread reads rowid[s] between the two barriers around here)
+                const int j = (v_next % ra.groups) * ROWS + s;
                 sm.rowid[s] = j < ra.rows_per_domain
-                                  ? (int)perm_apply((unsigned)(domain * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t + 1]) : -1;
+                                  ? (int)perm_apply((unsigned)((v_next / ra.groups) * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
                 sm.lrew[s] = 0.f;
             }
         }
@@ -1468,12 +1483,23 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         __syncthreads();
         prof.mark(10);
 
-        if (more && persist) {
-            // ---- collect the rows this workgroup owns in step t + 1: 8-byte {value bits, step tag} granules, self-validating ----
+        if (persist && has_next) {
+            // ---- collect the rows of the next turn: 8-byte {value bits, step tag} granules, self-validating ----
+            domain = v_next / ra.groups;
             compute_act_base();
             float av2[kPrefetch];
-            fetch_actions_issue(t + 1, av2);  // in flight while the rows arrive
-            const unsigned long long tag = handover_tag;
+            fetch_actions_issue(t_next, av2);  // in flight while the rows arrive
+            const unsigned long long tag = (unsigned long long)(ra.tag_base + (unsigned)t_next) << 32;  // published in step t_next - 1
+            if (t_next == ra.t_begin) {  // a later turn of the FIRST step: the rows start from s0 (nothing was handed over yet)
+                for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
+                    const int s_ = i / md.obs_dim;
+                    sm.state[i] = sm.rowid[s_] >= 0 ? ra.s0[i - s_ * md.obs_dim] : 0.f;
+                }
+                for (int s_ = tid; s_ < ROWS; s_ += kThreads) {
+                    sm.tot[s_] = 0.f;
+                    sm.term[s_] = 0;
+                }
+            } else
             for (int base = 0; base < ROWS * NV; base += kG * kThreads) {
                 const unsigned long long* src[kG];
                 unsigned long long g[kG];
@@ -1521,9 +1547,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                         else sm.term[gs[q]] = (int)bits;
                     }
             }
-            fetch_actions_commit(t + 1, av2);
+            fetch_actions_commit(t_next, av2);
             __syncthreads();
-            build_input(t + 1);
+            build_input(t_next);
             __syncthreads();
         }
     }
@@ -1531,7 +1557,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     // ---- write back -------------------------------------------------------------------------------
     for (int s = tid; s < ROWS; s += kThreads) {
         const int rid = sm.rowid[s];
-        if (rid < 0) continue;
+        if (rid < 0 || persist) continue;  // persistent form: written in the last step's reward phase
         ra.totals[rid] = sm.tot[s];
         if ((!fast && !persist) || (!kLean && ra.write_back)) ra.term[rid] = (unsigned char)sm.term[s];
     }

@@ -119,10 +119,16 @@ def test_device_mode_rejects_basic_ensemble_member_maps(engine):
         engine.rollout(a, np.zeros(17, np.float32), 2, mode="device")
 
 
-@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6]], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+# beyond the chip: more logical workgroups than CUs, served in turns by the launched ones (420 at R = 3; 1 250 one-tile workgroups
+# of a small model; a ragged last turn)
+BIG = [(17, 6, 1000, 20, 5, dict(hid=200)), (5, 2, 4000, 5, 4, dict(hid=32)), (17, 6, 650, 20, 3, dict(hid=200))]
+
+
+@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6]] + BIG, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
 def test_persistent_and_per_step_launches_agree_bitwise(engine, case):
-    """DEVICE-mode rollouts whose workgroups are all co-resident run as ONE launch with the rows handed over between workgroups
-    through tagged granules; forbidding that (one launch per step, state through HBM between kernels) must not change a bit."""
+    """DEVICE-mode rollouts run as ONE launch with the rows handed over between workgroups through tagged granules (batches
+    with more workgroups than CUs: every launched workgroup serves several logical ones per step); forbidding that (one launch
+    per step, state through HBM between kernels) must not change a bit."""
     obs, act, pop, P, H, mkw = case
     om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
     engine.set_model(to_spec(om, obs, act))
