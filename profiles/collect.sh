@@ -25,6 +25,12 @@ timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_
 for c in cfg1_cartpole cfg4_humanoid_truncated_obs cfg4_humanoid_v4_obs376 cfg5_cheetah_run planet cfg1_cem_plan cfg4_icem_plan cfg5_mppi_plan; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_$c -o t -- python profiles/other_configs.py --only $c --mode device --reps 5 > $OUT/cfg_$c.log 2>&1
 done
+# the separately reported bf16x3 arithmetic mode: kernel trace of cfg2 rollouts in both randomness modes, L2 hit / miss counters
+for MODE in device fast; do
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_cfg2_bf16x3_$MODE -o t -- python profiles/precision_probe.py --precision bf16x3 --mode $MODE --reps 10 > $OUT/cfg_cfg2_bf16x3_$MODE.log 2>&1
+done
+timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_tcc_bf16x3_device -o pmc -- python profiles/precision_probe.py --precision bf16x3 --mode device --reps 3 > $OUT/pmc_tcc_bf16x3_device.log 2>&1
 python profiles/other_configs.py --reps 6 > $OUT/other_configs.json 2> $OUT/other_configs.err
+python profiles/small_batch_probe.py > $OUT/small_batches.json 2> $OUT/small_batches.err
 find $OUT -name "*_kernel_stats.csv" | head -40
 find $OUT -name "*.csv" -size +2M -delete   # the per-dispatch traces are large; the stats summaries are what gets committed

@@ -107,6 +107,20 @@ for d_ in sorted(glob.glob(os.path.join(src, "cfg_*"))):
                                                            "pct": float(r["Percentage"])} for r in rows[:5]]}
 if cfgs:
     json.dump(cfgs, open(os.path.join(dst, f"{tag}_config_kernel_stats.json"), "w"), indent=1)
+sb = os.path.join(src, "small_batches.json")
+if os.path.exists(sb) and os.path.getsize(sb):
+    shutil.copy(sb, os.path.join(dst, f"{tag}_small_batches.json"))
+tcc = sorted(glob.glob(os.path.join(src, "pmc_tcc_bf16x3_device", "**", "pmc_counter_collection.csv"), recursive=True))
+if tcc:
+    acc = {}
+    for r in csv.DictReader(open(tcc[0])):
+        if "rollout_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    per = {k: sum(v[-3:]) / len(v[-3:]) for k, v in acc.items()}
+    if per.get("TCC_REQ_sum"):
+        per["l2_hit_frac"] = per.get("TCC_HIT_sum", 0.0) / (per.get("TCC_HIT_sum", 0.0) + per.get("TCC_MISS_sum", 1.0))
+    json.dump({"workload": "cfg2 rollout, precision bf16x3, DEVICE mode (persistent form, XCD-major workgroup order)", "per_launch": per},
+              open(os.path.join(dst, f"{tag}_bf16x3_l2.json"), "w"), indent=1)
 oc = os.path.join(src, "other_configs.json")
 if os.path.exists(oc) and os.path.getsize(oc):
     shutil.copy(oc, os.path.join(dst, f"{tag}_other_configs.json"))
