@@ -187,9 +187,11 @@ int hipets_fast_normals(hipets_engine* e, int32_t horizon, int32_t batch, uint64
 int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id, int64_t* perms,
                         void* stream);
 
-/* DEVICE-mode rollouts with a fresh permutation per step (random_model) run as ONE persistent launch when all their
- * workgroups are co-resident (<= one per CU): rows change workgroups every step through a table of 8-byte {value, step tag}
- * granules in HBM (write-through stores, polled loads; no grid barrier).  Larger batches launch once per step.  Every poll is
+/* DEVICE-mode rollouts with a fresh permutation per step (random_model) run as ONE persistent launch: only as many workgroups
+ * as are resident at once are launched, rows change workgroups every step through a table of 8-byte {value, step tag} granules
+ * in HBM (write-through stores, polled loads; no grid barrier), and a batch with more logical workgroups than that is served
+ * in turns by the launched ones (except where two workgroups fit a CU and the batch still exceeds the chip: those launch once
+ * per step).  Every poll is
  * bounded (0.2 s): if a producer never shows up the kernel raises a host-visible flag, the NEXT call on the engine fails with
  * that report and the engine falls back to per-step launches.  The persistent form assumes what the reference's deployment
  * gives it -- one planning process per GPU; processes or streams that share a GPU with other large kernels must switch it
