@@ -647,7 +647,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             HCHECK(hipGetLastError());
         }
         if (persistent) {
-            const size_t nv = (size_t)md.obs_dim + 2;
+            const size_t nv = 2 * ((size_t)(md.obs_dim + 1) / 2 + 1);  // granules per row: the state dims padded to pairs, then {total, flag}
             const size_t cap_before = e->exchange.cap;
             if (e->exchange.ensure((size_t)B * nv * 8)) return 1;
             // hand-over tags grow monotonically across launches (step t of this launch: tag_base + t + 1), so a granule left by an

@@ -172,6 +172,18 @@ struct NextOp {  // this wave's share of the op to prefetch for (wave-uniform)
 };
 // workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for global loads in flight
 // (__syncthreads() also drains vmcnt, which would expose the latency of the prefetched weight fragments at every barrier)
+// 16-byte write-through store / load of a PAIR of hand-over granules {value, tag, value, tag} (persistent DEVICE form).  sc1 =
+// device scope: the store leaves the XCD's L2, the load never returns a stale L1 line (MI355X_MICROARCH.md: 8-byte sc1 stores
+// cost 2.7x the 16-byte ones per byte, and a workgroup's polls queue behind its own stores).  The load is asynchronous:
+// pair_wait() is the s_waitcnt, tied to the destination registers so nothing reads them earlier.
+using u32x4g = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void pair_store(unsigned long long* p, const unsigned v0, const unsigned v1, const unsigned tag) {
+    const u32x4g d = {v0, tag, v1, tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ void pair_load_issue(u32x4g& d, const unsigned long long* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void prefetch_issue(const NextOp& n, const int lane, Pre& pre) {
     if (!n.valid) return;
@@ -948,6 +960,17 @@ __device__ __forceinline__ float softplus_fast(float x) {
 template <int R> struct MinWaves { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
 
 // S = KSpec<...>: the compile-time facts of this instance (generic: only the activation may be fixed; lean: the whole shape).
+// Profiling build only (-DHIPETS_STEP_TRACE, profiles/handover_trace.py): wall-clock stamps (100 MHz, chip-wide) of every
+// workgroup at four points of every step of the persistent DEVICE form, behind the phase-cycle table of the caller's buffer.
+#ifdef HIPETS_STEP_TRACE
+#define HIPETS_STAMP(k, step)                                                                                                     \
+    do {                                                                                                                          \
+        if (persist && ra.phase_cycles && tid == 0) ra.phase_cycles[128 + ((size_t)blockIdx.x * ra.H + (step)) * 4 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define HIPETS_STAMP(k, step) do {} while (0)
+#endif
+
 template <int R, class S>
 __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
@@ -1037,15 +1060,17 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     }
     const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
-    // exchange item i = (row slot i / NV, value i % NV): items tid + q * kThreads of a thread are the same every step
-    constexpr int kG = 4;  // granules in flight per thread and round
-    const int NV = md.obs_dim + 2;  // state dims, running total, terminated flag
+    // hand-over table row = NVP pairs of 8-byte granules: the state dims (padded to an even count), then {running total, flag}.
+    // exchange item i = (row slot i / NVP, pair i % NVP): items tid + q * kThreads of a thread are the same every step
+    constexpr int kG = 2;  // 16-byte pair loads in flight per thread and round (cfg2: 48 rows x 10 pairs = 480 items, one round)
+    const int NVP = (md.obs_dim + 1) / 2 + 1;  // pairs per row
+    const int NV = 2 * NVP;                    // granules per row
     int xs[kG], xv[kG];
 #pragma unroll
     for (int q = 0; q < kG; ++q) {
         const int i = tid + q * kThreads;
-        xs[q] = i < ROWS * NV ? i / NV : -1;
-        xv[q] = i < ROWS * NV ? i - (i / NV) * NV : 0;
+        xs[q] = i < ROWS * NVP ? i / NVP : -1;
+        xv[q] = i < ROWS * NVP ? i - (i / NVP) * NVP : 0;
     }
     if constexpr (kB3) {
         // bf16x3: the k chunks are 32 wide, the column tiles 16: the last chunk of a 13-tile layer ends in 16 columns no epilogue
@@ -1346,6 +1371,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
         // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
         // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
+        HIPETS_STAMP(0, t);  // the MLP is done
         unsigned long long* const handover = (more && persist) ? ra.exchange : nullptr;
         const unsigned long long handover_tag = (unsigned long long)(ra.tag_base + (unsigned)t + 1u) << 32;  // tags never repeat across launches
         auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
@@ -1390,18 +1416,24 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
                 }
                 (void)inv_m;
+                unsigned pub[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int d = blk * 4 + q;
                     if (d < md.obs_dim) {
                         const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
                         sm.state[s * md.obs_dim + d] = nobs;
-                        // persistent DEVICE form: the row's next owner waits for this value -- on its way before the reward phase
-                        if (handover) __hip_atomic_store(handover + (size_t)rid * NV + d, handover_tag | __float_as_uint(nobs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1, 8 B
+                        pub[q] = __float_as_uint(nobs);
                         if (trace_next_obs) trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
                     } else if (d < md.out_dim) {
                         sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
                     }
+                }
+                // persistent DEVICE form: the row's next owner waits for these values -- on their way before the reward phase
+                if (handover) {
+                    const unsigned tg = (unsigned)(handover_tag >> 32);
+                    if (blk * 4 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4, pub[0], pub[1], tg);
+                    if (blk * 4 + 2 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4 + 2, pub[2], pub[3], tg);
                 }
             }
         };
@@ -1435,27 +1467,24 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
                 float tot = sm.tot[s];
                 int trm = sm.term[s];
-                if (persist) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
-                    unsigned long long* const src = ra.exchange + (size_t)rid * NV + md.obs_dim;
-                    const unsigned long long want = (unsigned long long)(ra.tag_base + (unsigned)t);
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if (!sm.pend[k * ROWS + s]) continue;
-                        sm.pend[k * ROWS + s] = 0;
-                        const long long t_poll = wall_clock64();
-                        unsigned long long g = 0;
-                        for (int spins = 0;; ++spins) {
-                            g = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((g >> 32) == want) break;
-                            if ((spins & 63) == 63 && wall_clock64() - t_poll > 20000000ll) {
-                                *ra.error_flag = 1;
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(8);
+                if (persist && sm.pend[s]) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
+                    sm.pend[s] = 0;
+                    const unsigned long long* const src = ra.exchange + (size_t)rid * NV + (NV - 2);
+                    const unsigned want = ra.tag_base + (unsigned)t;
+                    const long long t_poll = wall_clock64();
+                    u32x4g g = {0u, 0u, 0u, 0u};
+                    for (int spins = 0;; ++spins) {
+                        pair_load_issue(g, src);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
+                        if (g[1] == want && g[3] == want) break;
+                        if ((spins & 63) == 63 && wall_clock64() - t_poll > 20000000ll) {
+                            *ra.error_flag = 1;
+                            break;
                         }
-                        if (k == 0) tot = __uint_as_float((unsigned)g);
-                        else trm = (int)(unsigned)g;
+                        __builtin_amdgcn_s_sleep(8);
                     }
+                    tot = __uint_as_float(g[0]);
+                    trm = (int)g[2];
                 }
                 float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
                 const bool done = term_eval(st, md.obs_dim, term_fn);
@@ -1466,8 +1495,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 sm.term[s] = trm;
                 sm.tot[s] = tot;
                 if (handover) {
-                    __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim, handover_tag | __float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(handover + (size_t)rid * NV + md.obs_dim + 1, handover_tag | (unsigned)trm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pair_store(handover + (size_t)rid * NV + (NV - 2), __float_as_uint(tot), (unsigned)trm, (unsigned)(handover_tag >> 32));
                 } else if (persist) {
                     ra.totals[rid] = tot;  // last step: the row's return
                 }
@@ -1483,6 +1511,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         __syncthreads();
         prof.mark(10);
 
+        HIPETS_STAMP(1, t);  // sampled, rewarded, published
         if (persist && has_next) {
             // ---- collect the rows of the next turn: 8-byte {value bits, step tag} granules, self-validating ----
             domain = v_next / ra.groups;
@@ -1500,32 +1529,40 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     sm.term[s_] = 0;
                 }
             } else
-            for (int base = 0; base < ROWS * NV; base += kG * kThreads) {
+            for (int base = 0; base < ROWS * NVP; base += kG * kThreads) {
                 const unsigned long long* src[kG];
-                unsigned long long g[kG];
+                u32x4g g[kG];
                 int gs[kG], gv[kG];
-                bool soft[kG];  // running total / flag: wanted at the NEXT reward phase only -- one look now, the rest there
+                bool soft[kG];  // {running total, flag}: wanted at the NEXT reward phase only -- one look now, the rest there
+                const unsigned want = (unsigned)(tag >> 32);
 #pragma unroll
                 for (int q = 0; q < kG; ++q) {
                     const int i = base + tid + q * kThreads;
-                    gs[q] = base == 0 ? xs[q] : (i < ROWS * NV ? i / NV : -1);
-                    gv[q] = base == 0 ? xv[q] : (i < ROWS * NV ? i - (i / NV) * NV : 0);
-                    soft[q] = gv[q] >= md.obs_dim;
+                    gs[q] = base == 0 ? xs[q] : (i < ROWS * NVP ? i / NVP : -1);
+                    gv[q] = base == 0 ? xv[q] : (i < ROWS * NVP ? i - (i / NVP) * NVP : 0);
+                    soft[q] = gv[q] == NVP - 1;
                     src[q] = nullptr;
-                    g[q] = tag;  // rows of the padding: zero state, total, flag
+                    g[q] = u32x4g{0u, want, 0u, want};  // rows of the padding: zero state, total, flag
                     if (gs[q] >= 0) {
                         const int rid = sm.rowid[gs[q]];
-                        if (rid >= 0) src[q] = ra.exchange + (size_t)rid * NV + gv[q];
+                        if (rid >= 0) src[q] = ra.exchange + (size_t)rid * NV + 2 * gv[q];
                     }
                 }
                 const long long t_poll = wall_clock64();  // constant 100 MHz counter
                 for (int spins = 0;; ++spins) {
+                    // issue, issue, wait as straight-line asm (no branch between a load and its wait: the compiler does not know the
+                    // destination registers are still in flight); items with nothing to fetch read the table's first pair and ignore it
+                    static_assert(kG == 2, "the wait below names the two destinations");
+                    u32x4g got[kG];
+                    pair_load_issue(got[0], src[0] ? src[0] : ra.exchange);
+                    pair_load_issue(got[1], src[1] ? src[1] : ra.exchange);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1])::"memory");
                     bool ready = true;
 #pragma unroll
                     for (int q = 0; q < kG; ++q)
                         if (src[q]) {
-                            g[q] = __hip_atomic_load(src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1 line
-                            if ((g[q] >> 32) == (tag >> 32)) src[q] = nullptr;
+                            g[q] = got[q];
+                            if (got[q][1] == want && got[q][3] == want) src[q] = nullptr;
                             else if (!soft[q]) ready = false;
                         }
                     if (ready) break;
@@ -1540,17 +1577,24 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 #pragma unroll
                 for (int q = 0; q < kG; ++q)
                     if (gs[q] >= 0) {
-                        const unsigned bits = (unsigned)g[q];
-                        if (gv[q] < md.obs_dim) sm.state[gs[q] * md.obs_dim + gv[q]] = __uint_as_float(bits);
-                        else if (src[q]) sm.pend[(gv[q] - md.obs_dim) * ROWS + gs[q]] = 1;  // not there yet: the reward phase fetches it
-                        else if (gv[q] == md.obs_dim) sm.tot[gs[q]] = __uint_as_float(bits);
-                        else sm.term[gs[q]] = (int)bits;
+                        if (!soft[q]) {
+                            const int d = 2 * gv[q];
+                            sm.state[gs[q] * md.obs_dim + d] = __uint_as_float(g[q][0]);
+                            if (d + 1 < md.obs_dim) sm.state[gs[q] * md.obs_dim + d + 1] = __uint_as_float(g[q][2]);
+                        } else if (src[q]) {
+                            sm.pend[gs[q]] = 1;  // not there yet: the reward phase fetches the pair
+                        } else {
+                            sm.tot[gs[q]] = __uint_as_float(g[q][0]);
+                            sm.term[gs[q]] = (int)g[q][2];
+                        }
                     }
             }
+            HIPETS_STAMP(2, t);  // this thread's rows have arrived
             fetch_actions_commit(t_next, av2);
             __syncthreads();
             build_input(t_next);
             __syncthreads();
+            HIPETS_STAMP(3, t);  // the next step's input is built
         }
     }
 
