@@ -25,7 +25,7 @@ actions = (torch.rand(pop, H, bench.ACT, generator=g) * 2 - 1).to(dev)
 s0 = np.zeros(bench.OBS, np.float32)
 NWG = 256
 buf = torch.zeros(128 + NWG * H * 4, dtype=torch.int64, device=dev)
-for i in range(5):
+for i in range(200):  # warm the clocks up (the first rollouts after idle run ~5 % slower)
     eng.rollout(actions, s0, P, mode="device", seed=1, stream_id=i)
 res = []
 for rep in range(5):
@@ -51,5 +51,13 @@ for rep in range(5):
         "earliest arrival - latest publish (negative: somebody already had its rows before the slowest finished)": float((arrived.min(0) - published.max(0)).mean()),
         "MLP + tail of a step (built(t-1) -> published(t)) mean": float((published[:, 1:] - built[:, :-1]).mean()),
         "per-XCD mean step length": [float(step_len[np.arange(n) % 8 == x].mean()) for x in range(8)],
+        # is a workgroup late systematically (same CU / position every step) or at random?  lateness = published - step median
+        "lateness of 'published' per workgroup: std over workgroups of the per-workgroup MEAN / mean over workgroups of the per-workgroup STD": [
+            float((published - np.median(published, axis=0)).mean(1).std()), float((published - np.median(published, axis=0)).std(1).mean())],
+        "per-workgroup mean lateness in block order (us)": [round(float(x), 2) for x in (published - np.median(published, axis=0)).mean(1)],
+        "per-workgroup mean MLP duration in block order (us)": [round(float(x), 2) for x in (st[:, 1:H - 1, 0] - built[:, :-1]).mean(1)],
+        "per-workgroup mean lateness, sorted (us)": [round(float(x), 2) for x in np.sort((published - np.median(published, axis=0)).mean(1))[::10]],
+        "MLP duration (built(t-1) -> MLP done(t)): mean, std over workgroups of per-workgroup mean, mean per-workgroup std over steps": [
+            float((st[:, 1:H - 1, 0] - built[:, :-1]).mean()), float((st[:, 1:H - 1, 0] - built[:, :-1]).mean(1).std()), float((st[:, 1:H - 1, 0] - built[:, :-1]).std(1).mean())],
     })
 print(json.dumps({"lib": os.environ.get("HIPETS_LIB", "default"), "runs": res}))
