@@ -21,8 +21,9 @@
  *     they read caller-owned DEVICE tensors that may be freed right after the call: hipets_set_model
  *     and hipets_planet_set_model.  hipets_timing_read waits for the events it reports.  Nothing else
  *     synchronises.
- *   - HOST arrays (observations, descriptors) are consumed before the call returns (small pageable
- *     hipMemcpyAsync H2D copies are staged by the runtime at enqueue time), so temporaries are fine.
+ *   - HOST arrays are consumed before the call returns, so temporaries are fine: observations are copied into
+ *     pinned staging buffers owned by the engine and uploaded asynchronously from there; model descriptors are
+ *     uploaded inside hipets_set_model, which synchronises.
  *   - one engine per device; an engine is not thread-safe (the reference is single-threaded).
  */
 #ifndef HIPETS_H

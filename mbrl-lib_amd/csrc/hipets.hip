@@ -79,6 +79,11 @@ struct hipets_engine {
     DevBuf s0, state, totals, term, schedule, plan_schedule;
     // DEVICE mode, persistent form: row exchange table, per-step permutation keys, timeout flag (host-mapped)
     DevBuf exchange, step_keys, plan_keys;
+    // host -> device staging of the caller's observations: a small ring of pinned buffers owned by the engine, so the async
+    // copy never reads caller memory after the call returned (hipets.h: HOST arrays are consumed during the call)
+    struct HostStage { void* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    HostStage stage[4];
+    int stage_next = 0;
     uint32_t tag_base = 0;  // hand-over tags handed out so far (exchange granules hold tags <= tag_base)
     // the key tables a fused plan generated up front: rollouts (plan_keys_seed, stream in [first, first + count), H) read them
     uint64_t plan_keys_seed = 0, plan_keys_first = 0;
@@ -175,13 +180,34 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
 }
 
 // Plan-level prologue shared by the fused plans: stage the observation(s) once and, for member-sampling propagation,
+// copy `bytes` of caller HOST memory to `dst` on `st`: memcpy into the next pinned slot of the engine's ring, async copy from
+// there.  A slot is reused only after the copy that last read it has executed (its event; normally long complete).
+int stage_h2d(hipets_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    hipets_engine::HostStage& sl = e->stage[e->stage_next];
+    e->stage_next = (e->stage_next + 1) % 4;
+    if (sl.used) HCHECK(hipEventSynchronize(sl.done));
+    if (bytes > sl.cap) {
+        if (sl.p) (void)hipHostFree(sl.p);
+        sl.p = nullptr;
+        sl.cap = 0;
+        HCHECK(hipHostMalloc(&sl.p, bytes < 4096 ? 4096 : bytes, hipHostMallocDefault));
+        sl.cap = bytes < 4096 ? 4096 : bytes;
+    }
+    if (!sl.done) HCHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    std::memcpy(sl.p, src, bytes);
+    HCHECK(hipMemcpyAsync(dst, sl.p, bytes, hipMemcpyHostToDevice, st));
+    HCHECK(hipEventRecord(sl.done, st));
+    sl.used = true;
+    return 0;
+}
+
 // generate the member schedules of `iters` consecutive FAST rollouts (stream ids first_stream, +1, ...) of `pop` candidates
 // in ONE launch.  *sched = schedule of rollout 0 (rollout i: + i * H * nwg) or nullptr (expectation propagation).
 int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, int H, int iters, uint64_t seed, uint64_t first_stream,
                   hipStream_t st, const int** sched, size_t* sched_stride) {
     const ModelDev& md = e->md;
     if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
-    HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    if (stage_h2d(e, e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, st)) return 1;
     *sched = nullptr;
     *sched_stride = 0;
     if (md.propagation == HIPETS_PROP_RANDOM_MODEL && iters >= 1 && e->plan_mode == HIPETS_MODE_DEVICE && e->persistent_ok) {
@@ -351,6 +377,10 @@ void hipets_destroy(hipets_engine* e) {
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->error_flag) (void)hipHostFree(e->error_flag);
+    for (auto& sl : e->stage) {
+        if (sl.p) (void)hipHostFree(sl.p);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     delete e;
 }
 
@@ -559,7 +589,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         return fail("n_env %d needs FAST mode and a population (%d) divisible by it", n_env, pop);
     if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
     if (e->totals.ensure((size_t)B * 4)) return 1;
-    if (s0) HCHECK(hipMemcpyAsync(e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    if (s0 && stage_h2d(e, e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, st)) return 1;
 
     RolloutArgs ra{};
     ra.pop = pop; ra.P = P; ra.H = H; ra.B = (int)B;
@@ -1140,7 +1170,7 @@ int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int3
     ro.seed = seed;
     ro.n_env = n_env;
     if (e->s0.ensure(ne * e->md.obs_dim * 4)) return 1;  // the observations are the same for every iteration: stage them once
-    HCHECK(hipMemcpyAsync(e->s0.p, s0, ne * e->md.obs_dim * 4, hipMemcpyHostToDevice, st));
+    if (stage_h2d(e, e->s0.p, s0, ne * e->md.obs_dim * 4, st)) return 1;
     float* popbuf = e->population.as<float>();  // [n_env][rows][H][A], rows = this iteration's candidates per environment
     for (int i = 0; i < iters; ++i) {
         const int n = sizes[i];
