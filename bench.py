@@ -38,6 +38,7 @@ import torch  # noqa: E402
 
 OBS, ACT, ENSEMBLE, HID, LAYERS = 17, 6, 5, 200, 4
 POP, HORIZON, PARTICLES, ITERS, ELITE_RATIO, ALPHA = 500, 30, 20, 5, 0.1, 0.1
+METRIC = "candidate-steps/sec (pop\u00d7particles\u00d7horizon / plan) per CEM iter; plans/sec"  # BASELINE.json's metric, verbatim
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
 
 
@@ -425,7 +426,7 @@ def main():
     else:
         workload = (f"configs[1] scaled weakly: pop {pop} = {POP} per rank over {world} GPUs (configs[2] is the `cfg3_strong` block)")
     out = {
-        "metric": "candidate-steps/sec (pop x particles x horizon / plan) per CEM iter; plans/sec",
+        "metric": METRIC,
         "value": value, "unit": "candidate-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -1,0 +1,77 @@
+"""The bench line the repository ships (profiles/r2_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
+contract and is internally consistent: the roofline block follows from the algorithmic FLOP count and the measured launch
+time, `value` from the plan time, the metric / workload are BASELINE.json's.  (CPU test: reads committed files only.)"""
+import json
+import os
+
+import pytest
+
+from conftest import ROOT
+
+
+def _line():
+    return json.load(open(os.path.join(ROOT, "profiles", "r2_bench_line.json")))
+
+
+def test_contract_keys_and_types():
+    d = _line()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"].replace(" x ", "\u00d7") == base["metric"]  # lines recorded before the metric was spelled verbatim used " x "
+    assert d["unit"] == "candidate-steps/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] >= 1 and d["warmup"] >= 0
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None  # BASELINE.md publishes no number
+    assert d["scaling"] in ("weak", "strong")
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    for k in ("roofline", "cpu_baseline"):
+        assert isinstance(d[k], dict)
+
+
+def test_value_follows_from_the_plan_time():
+    d = _line()
+    cs_per_plan = d["config"]["candidate_steps_per_plan"]
+    assert cs_per_plan == 5 * 500 * 20 * 30  # CEM iterations x pop x particles x horizon (BASELINE.json configs[1])
+    assert d["value"] == pytest.approx(cs_per_plan / (d["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_roofline_block_is_consistent():
+    r = _line()["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    # 2 (in hid + 3 hid^2 + hid 2 out) FLOP per candidate-step at cfg2
+    assert r["flops_per_candidate_step"] == 2 * (23 * 200 + 3 * 200 * 200 + 200 * 34) == 262800
+    assert r["algorithmic_flops_per_launch"] == 262800 * 500 * 20 * 30
+    assert r["achieved"] == pytest.approx(r["algorithmic_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    assert 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+
+
+def test_rocprof_summary_agrees_with_the_live_measurement():
+    """profiles/r2_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
+    import csv
+
+    r = _line()["roofline"]
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_kernel_stats_device.csv"))))
+    roll = [x for x in rows if "rollout_kernel" in x["Name"]]
+    assert roll, "no rollout kernel in the committed rocprofv3 statistics"
+    avg_ms = float(roll[0]["AverageNs"]) * 1e-6
+    assert avg_ms == pytest.approx(r["avg_launch_ms"], rel=0.02)
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert r["traffic"] == pytest.approx(traffic["rollout_kernel_bytes_per_launch_device"], rel=1e-9)
+
+
+def test_cpu_baseline_block():
+    c = _line()["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "candidate-steps/s"
+    assert c["plans_timed"] >= 5 and c["value_median"] <= c["value"] * 1.0000001  # best >= median
+    assert "sample" in c and "host" in c
+
+
+def test_bench_constants_are_the_baseline_config():
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert (bench.OBS, bench.ACT, bench.POP, bench.HORIZON, bench.PARTICLES, bench.ITERS) == (17, 6, 500, 30, 20, 5)
+    assert bench.PEAK_FP32_TFLOPS == 157.3
+    assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
