@@ -1027,7 +1027,11 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     // all of them (bf16x3: 0.83 MB per member, all five = 4.2 MB do not fit one L2).  Any bijection is correct.
     int wg = blockIdx.x;
     if (!fast) {
+#ifdef HIPETS_XCD_ROT  // profiling builds, grids that are multiples of 8 only: which XCD hosts which logical range (is a slow range slow because of the XCD or the member?)
+        const int nwg = gridDim.x, x = ((wg & 7) + HIPETS_XCD_ROT) & 7, slot = wg >> 3;
+#else
         const int nwg = gridDim.x, x = wg & 7, slot = wg >> 3;
+#endif
         wg = x * (nwg >> 3) + min(x, nwg & 7) + slot;
     }
 

@@ -20,7 +20,7 @@ dev = torch.device("cuda:0")
 eng = hipets.get_engine(dev)
 eng.set_model(bench.synthetic_spec(dev))
 g = torch.Generator().manual_seed(0)
-pop, H, P = bench.POP, bench.HORIZON, bench.PARTICLES
+pop, H, P = int(os.environ.get("HANDOVER_POP", bench.POP)), bench.HORIZON, bench.PARTICLES
 actions = (torch.rand(pop, H, bench.ACT, generator=g) * 2 - 1).to(dev)
 s0 = np.zeros(bench.OBS, np.float32)
 NWG = 256
@@ -60,4 +60,4 @@ for rep in range(5):
         "MLP duration (built(t-1) -> MLP done(t)): mean, std over workgroups of per-workgroup mean, mean per-workgroup std over steps": [
             float((st[:, 1:H - 1, 0] - built[:, :-1]).mean()), float((st[:, 1:H - 1, 0] - built[:, :-1]).mean(1).std()), float((st[:, 1:H - 1, 0] - built[:, :-1]).std(1).mean())],
     })
-print(json.dumps({"lib": os.environ.get("HIPETS_LIB", "default"), "runs": res}))
+print(json.dumps({"lib": os.environ.get("HIPETS_LIB", "default"), "pop": pop, "runs": res}))
