@@ -75,3 +75,19 @@ def test_bench_constants_are_the_baseline_config():
     assert (bench.OBS, bench.ACT, bench.POP, bench.HORIZON, bench.PARTICLES, bench.ITERS) == (17, 6, 500, 30, 20, 5)
     assert bench.PEAK_FP32_TFLOPS == 157.3
     assert bench.METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+
+
+def test_pmc_summary_counts_the_kernel_this_repository_ships():
+    """profiles/r2_rollout_pmc.json: SQ_INSTS_MFMA per launch equals the count derived from the kernel's structure -- 2178
+    v_mfma_f32_16x16x4_f32 per row-tile-step at cfg2 (input 13x6 + 3 x 13x50 + output 3x50 column-tile k-steps) x row tiles x
+    horizon: 210 workgroups x 3 tiles in DEVICE mode (5 members x 42 groups), 220 x 3 in FAST mode (11 candidate groups x 20
+    particles).  A counter file from another kernel or another workload would not reproduce these integers."""
+    per_tile_step = 13 * 6 + 3 * 13 * 50 + 3 * 50
+    assert per_tile_step == 2178
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_rollout_pmc.json")))
+    assert pmc["device"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (5 * 42 * 3) * 30
+    assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (11 * 20 * 3) * 30
+    for mode in ("device", "fast"):
+        d = pmc[mode]["derived"]
+        assert 0.4 < d["mfma_pipe_busy_frac_on_active_simds"] < 1.0
+        assert d["hbm_bytes_per_launch"] > 2.9e6  # at least the weight pack once
