@@ -227,6 +227,9 @@ def main():
             try:
                 hdist.init_engine_comm(engine)  # the library's own RCCL communicator; torch.distributed only carried the id
                 sharded = "library"
+                seen_rank, seen_world = engine.comm_info()  # ncclCommUserRank / ncclCommCount of the communicator the plans run on
+                comm_info["world_seen"] = seen_world
+                assert (seen_rank, seen_world) == (rank, world), f"communicator reports rank {seen_rank} of {seen_world}, launched as {rank} of {world}"
             except Exception as exc:  # SURVEY.md section 5 "failure detection": RCCL error -> single-GPU plans + a report
                 sharded = "fallback"
                 comm_info["fallback_reason"] = f"hipets_comm_init failed: {str(exc)[:200]}"
@@ -316,7 +319,9 @@ def main():
             except Exception:
                 traffic = None
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_FP32_TFLOPS) if ach else None,
-                "traffic": traffic, "kernel": "hipets::rollout_kernel", "launches": launches, "avg_launch_ms": 1e3 * avg_s if launches else None,
+                "traffic": traffic, "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE / WRITE_SIZE PMC passes of the same command (profiles/collect.sh), "
+                                                      "gfx950 correction of MI355X_MICROARCH.md; read from the committed file, NOT measured by this run",
+                "kernel": "hipets::rollout_kernel", "launches": launches, "avg_launch_ms": 1e3 * avg_s if launches else None,
                 "algorithmic_flops_per_launch": alg, "flops_per_candidate_step": flops_cs,
                 "launch_covers": f"{local_pop} candidates x {PARTICLES} particles x {steps_per_launch} step(s)",
                 "launches_timed": "every launch of the timed region" if stride == 1 else f"every {stride}-th launch of the timed region"}
@@ -325,6 +330,21 @@ def main():
     pop = POP * world if (world > 1 and args.scaling == "weak") else POP
     elapsed, launches, kernel_ms, spl, stride = run(args.mode, pop, args.steps, args.warmup)
     roof = roofline_block(args.mode, pop, launches, kernel_ms, spl, stride)
+    if world > 1:
+        # every rank's own rollout kernel: its shard (the first pop % world ranks hold one more candidate), its average launch
+        # duration from its own hipEvents, priced against the same per-candidate-step FLOP count.  `roofline` above is rank 0's
+        # view with the LARGEST shard; this makes a multi-GPU line self-explaining (which rank is slow, how small the shards are)
+        lo_, hi_ = hdist.shard_bounds(pop, world, rank) if sharded != "fallback" else (0, pop)
+        mine = {"rank": rank, "candidates": hi_ - lo_, "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
+                "achieved_tflops": (flops_cs * (hi_ - lo_) * PARTICLES * spl / (kernel_ms / max(launches, 1) * 1e-3) / 1e12) if launches else None}
+        mine["frac_of_fp32_peak"] = mine["achieved_tflops"] / PEAK_FP32_TFLOPS if mine["achieved_tflops"] else None
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        roof["per_rank"] = box
+        if args.scaling == "strong":
+            comm_info["north_star_target_8gpu_over_1gpu"] = 6.0
+            comm_info["design_prediction_8gpu_over_1gpu_strong"] = ("1.9-2.0x: a 63-candidate shard is 80 one-tile workgroups whose step is a ~17-20 us "
+                                                                    "latency chain whatever the batch (DESIGN.md section 7); >= 6x holds for the weak-scaled plan only")
     extras = {}
     other = "fast" if args.mode == "device" else "device"
     if not args.no_extras:

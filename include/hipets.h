@@ -16,11 +16,12 @@
  *   - pointers marked DEVICE point into caller-owned HBM (e.g. torch storage); pointers marked
  *     HOST are read during the call only.  The library retains no caller pointer past a call,
  *     except hipets_set_model which copies weights into its own packed layout.
- *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is
- *     enqueued asynchronously on it.  Two entry points synchronise `stream` before returning, because
- *     they read caller-owned DEVICE tensors that may be freed right after the call: hipets_set_model
- *     and hipets_planet_set_model.  hipets_timing_read waits for the events it reports.  Nothing else
- *     synchronises.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is enqueued asynchronously on it.
+ *     An engine's workspace is shared by its calls, so their work executes in call order: a call on another stream than the
+ *     previous call's makes its stream wait (device side) for that call's work.  Two entry points synchronise `stream` before
+ *     returning, because they read caller-owned DEVICE tensors that may be freed right after the call: hipets_set_model and
+ *     hipets_planet_set_model.  hipets_timing_read waits for the events it reports; the one-time co-residency self-test of a
+ *     persistent DEVICE-mode kernel instance synchronises once (hipets_set_persistent).  Nothing else synchronises.
  *   - HOST arrays are consumed before the call returns, so temporaries are fine: observations are copied into
  *     pinned staging buffers owned by the engine and uploaded asynchronously from there; model descriptors are
  *     uploaded inside hipets_set_model, which synchronises.
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HIPETS_ABI_VERSION 2
+#define HIPETS_ABI_VERSION 3
 #define HIPETS_MAX_LAYERS 8
 
 typedef struct hipets_engine hipets_engine;
@@ -189,15 +190,26 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
                         void* stream);
 
 /* DEVICE-mode rollouts with a fresh permutation per step (random_model) run as ONE persistent launch: only as many workgroups
- * as are resident at once are launched, rows change workgroups every step through a table of 8-byte {value, step tag} granules
- * in HBM (write-through stores, polled loads; no grid barrier), and a batch with more logical workgroups than that is served
- * in turns by the launched ones (except where two workgroups fit a CU and the batch still exceeds the chip: those launch once
- * per step).  Every poll is
- * bounded (0.2 s): if a producer never shows up the kernel raises a host-visible flag, the NEXT call on the engine fails with
- * that report and the engine falls back to per-step launches.  The persistent form assumes what the reference's deployment
- * gives it -- one planning process per GPU; processes or streams that share a GPU with other large kernels must switch it
- * off: on = 0 forces per-step launches (also: env HIPETS_NO_PERSISTENT=1).                                               */
+ * as are resident at once are launched, rows change workgroups every step through a table of 16-byte {value, tag, value, tag}
+ * granule pairs in HBM (write-through stores, polled loads; no grid barrier), and a batch with more logical workgroups than that
+ * is served in turns by the launched ones (except where two workgroups fit a CU and the batch still exceeds the chip: those
+ * launch once per step).  What makes that safe:
+ *   - residency is VERIFIED, not assumed: the first time a kernel instance is to run persistently at a larger grid than before,
+ *     the library launches that very instance in a self-test mode in which every workgroup waits for all the others (one extra
+ *     launch and ONE synchronisation of `stream`, once per instance and grid size); if they cannot meet, the runtime's smaller
+ *     occupancy answer is tried, and failing that the engine launches per step;
+ *   - every poll is bounded (hipets_set_handover_timeout, default 0.2 s): if a producer never shows up (another process or
+ *     stream took CUs after the self-test) the kernel raises a host-visible flag and drains in milliseconds.  The results of
+ *     that launch, and everything computed from them, are INVALID;
+ *   - hipets_check_async_error tells: call it once the results have reached the host (after the device-to-host copy of a plan,
+ *     or any synchronisation of `stream`), before acting on them.  On *timed_out = 1 the engine has already fallen back to
+ *     per-step launches: re-run the call (hipets.planning does exactly this).  A caller that never asks gets the report as an
+ *     error from its NEXT rollout / plan call instead.
+ * The persistent form assumes what the reference's deployment gives it -- one planning process per GPU; on = 0 forces per-step
+ * launches (also: env HIPETS_NO_PERSISTENT=1).                                                                             */
 int hipets_set_persistent(hipets_engine* e, int32_t on);
+int hipets_set_handover_timeout(hipets_engine* e, double seconds);
+int hipets_check_async_error(hipets_engine* e, int32_t* timed_out);
 
 /* ---- CEMOptimizer pieces (mbrl/planning/trajectory_opt.py:100-188) ------------------------- */
 typedef struct {
@@ -340,11 +352,18 @@ int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int3
 int hipets_comm_unique_id(void* id_out);
 int hipets_comm_init(hipets_engine* e, const void* unique_id, int32_t rank, int32_t world_size);
 int hipets_comm_destroy(hipets_engine* e);
+/* rank and size as the communicator itself reports them (ncclCommUserRank / ncclCommCount); 0 / 1 without a communicator.
+ * Env HIPETS_RCCL_LIB=<path> makes the library load that shared object instead of librccl (tests/fake_rccl builds a stand-in
+ * that runs N ranks as N processes on ONE GPU, so the world > 1 path of hipets_plan_cem_sharded is testable on a 1-GPU box). */
+int hipets_comm_info(hipets_engine* e, int32_t* rank, int32_t* world_size);
 /* hipets_plan_cem over all ranks of the communicator as one device-side loop per rank: every rank passes IDENTICAL
  * arguments; the population is sampled identically everywhere (counter-based RNG), rank r rolls out candidates
  * [r * pop / world ...) (first pop % world ranks hold one more), one ncclAllGather of the per-candidate returns per
  * iteration over xGMI, then the same refit on the same data everywhere (bit-identical mu / dispersion, no broadcast).
- * With world_size == 1 it equals hipets_plan_cem.                                                                          */
+ * With world_size == 1 it equals hipets_plan_cem.  Shard sizes that the rollout mode cannot take (DEVICE mode: rows % members)
+ * are refused on every rank before the first collective; a rank on which an iteration cannot be enqueued keeps taking part in
+ * the collectives and returns its error at the end (no peer is left waiting) -- agree on the outcome across ranks before using
+ * a plan (hipets.dist.plan_cem_sharded does).  hipets_set_plan_trace records the gathered values like hipets_plan_cem's.   */
 int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
                             const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id, float* out, void* stream);
 

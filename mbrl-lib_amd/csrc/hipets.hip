@@ -90,6 +90,15 @@ struct hipets_engine {
     int plan_keys_count = 0, plan_keys_H = 0;
     int* error_flag = nullptr;
     bool persistent_ok = true;
+    long long poll_ticks = 20000000ll;  // bound of one hand-over poll, 100 MHz ticks (hipets_set_handover_timeout; default 0.2 s)
+    DevBuf census;                      // [2] ints of the co-residency self-test (rollout_inst.inc launch_one)
+    // The workspace (state / totals / schedules / plan buffers), the hand-over table, its tags and the key tables are
+    // engine-global: the work of two calls must execute in the order the calls were made.  A call on another stream than the
+    // previous call's first makes its stream wait for that one (an event, device side only), so "any stream per call"
+    // (hipets.h) stays true without two launches ever sharing a buffer.
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
+    hipEvent_t last_done = nullptr;
     // plan workspace
     DevBuf mu, disp, population, values, best_value, best_solution, past_action, kept, elite_idx, keep_idx;
     // RCCL communicator (lazy-loaded librccl)
@@ -201,6 +210,20 @@ int stage_h2d(hipets_engine* e, void* dst, const void* src, size_t bytes, hipStr
     return 0;
 }
 
+// Every entry point that enqueues work on the engine's workspace calls this first: if `st` is not the stream of the previous
+// call, `st` waits (device side) for what that call enqueued.  Same stream: nothing to do.
+int enter_stream(hipets_engine* e, hipStream_t st) {
+    if (e->last_stream_set && e->last_stream != st) {
+        if (!e->last_done) HCHECK(hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming));
+        // the previous stream may have been destroyed by its owner meanwhile: then there is nothing left to wait for
+        if (hipEventRecord(e->last_done, e->last_stream) == hipSuccess) HCHECK(hipStreamWaitEvent(st, e->last_done, 0));
+        else (void)hipGetLastError();
+    }
+    e->last_stream = st;
+    e->last_stream_set = true;
+    return 0;
+}
+
 // generate the member schedules of `iters` consecutive FAST rollouts (stream ids first_stream, +1, ...) of `pop` candidates
 // in ONE launch.  *sched = schedule of rollout 0 (rollout i: + i * H * nwg) or nullptr (expectation propagation).
 int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, int H, int iters, uint64_t seed, uint64_t first_stream,
@@ -243,15 +266,24 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;     // optional (hipets_comm_info)
+    int (*CommUserRank)(void*, int*) = nullptr;  // optional
 };
 Rccl g_rccl;
 
 int rccl_load() {
     if (g_rccl.lib) return 0;
     void* lib = nullptr;
+    // HIPETS_RCCL_LIB=<path>: load THIS library instead (a site build of RCCL; tests/fake_rccl: a stand-in that implements the
+    // five entry points for N processes sharing one GPU, so that the world > 1 path runs on a one-GPU box)
+    const char* forced = std::getenv("HIPETS_RCCL_LIB");
+    if (forced && forced[0]) {
+        lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return fail("cannot load the RCCL library named by HIPETS_RCCL_LIB (%s): %s", forced, dlerror());
+    }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (lib) break;
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!lib) return fail("cannot load librccl: %s", dlerror());
     g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclGetUniqueId"));
@@ -259,6 +291,8 @@ int rccl_load() {
     g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
     g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(lib, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(lib, "ncclGetErrorString"));
+    g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(lib, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<int (*)(void*, int*)>(dlsym(lib, "ncclCommUserRank"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) return fail("librccl lacks an expected symbol");
     g_rccl.lib = lib;
     return 0;
@@ -362,6 +396,7 @@ int hipets_create(int device, hipets_engine** out) {
     if (e->error_flag) *e->error_flag = 0;
     const char* np = std::getenv("HIPETS_NO_PERSISTENT");
     e->persistent_ok = e->error_flag != nullptr && !(np && np[0] == '1');
+    if (e->census.ensure(2 * sizeof(int))) e->persistent_ok = false;
     *out = e;
     return 0;
 }
@@ -372,11 +407,12 @@ void hipets_destroy(hipets_engine* e) {
     if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
     for (DevBuf* b : {&e->w3pack, &e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
                       &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->plan_keys, &e->mu, &e->disp, &e->population, &e->values,
-                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered})
+                      &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered, &e->census})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (e->error_flag) (void)hipHostFree(e->error_flag);
+    if (e->last_done) (void)hipEventDestroy(e->last_done);
     for (auto& sl : e->stage) {
         if (sl.p) (void)hipHostFree(sl.p);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -388,6 +424,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     if (!e || !d) return fail("null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     if (d->n_layers < 2 || d->n_layers > HIPETS_MAX_LAYERS) return fail("n_layers %d outside [2, %d]", d->n_layers, HIPETS_MAX_LAYERS);
     if (d->n_members < 1 || d->n_members > d->ensemble_size) return fail("n_members %d invalid for ensemble_size %d", d->n_members, d->ensemble_size);
     if (d->obs_dim < 1 || d->act_dim < 1 || d->in_dim < d->act_dim + 1 || d->hid < 1) return fail("bad dimensions");
@@ -575,10 +612,12 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         *e->error_flag = 0;
         e->persistent_ok = false;  // fall back to one launch per step from now on
         return fail("a persistent DEVICE-mode rollout timed out waiting for rows of another workgroup (its workgroups were not all "
-                    "resident); the results of that call are invalid.  Persistent launches are now disabled for this engine.");
+                    "resident) and nobody asked (hipets_check_async_error after the results were read): the results of that earlier "
+                    "call are invalid.  Persistent launches are now disabled for this engine.");
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const ModelDev& md = e->md;
     const long long B = (long long)pop * P;
     if (B > 0x7FFFFFFF / std::max(md.obs_dim, md.out_dim)) return fail("batch too large");
@@ -659,16 +698,27 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         // table.  Only as many workgroups as are resident at once are launched; a batch with more logical workgroups (cfg4: 435)
         // is served in turns, workgroup b taking b, b + grid, ... every step.
         bool persistent = device && per_step && e->persistent_ok && H > 1;
-        if (persistent && domains * groups > e->num_cu) {
-            // Turns pay off when a CU holds ONE workgroup of this instance (cfg4: 4.51 -> 4.11 ms per rollout, cfg4' 16.4 -> 15.0).
-            // Where two are resident, one launch per step lets the hardware deal 1 250 workgroups to 512 slots as they free up;
-            // fixed turns (3 for some workgroups, 2 for the rest) measured slower there (cfg5: 7.3 vs 6.6 ms).
+        if (persistent) {
+            // How many workgroups of this kernel instance can wait for each other (be resident at once)?  The launcher answers
+            // from the occupancy arithmetic AND a one-time self-test of the instance at this grid size (a census launch + one
+            // stream synchronisation the first time a larger grid is asked for); 0 = the self-test failed (CUs held by another
+            // process, a masked device, an occupancy estimate that does not hold on this ROCm build): launch per step then.
             int capacity = 0;
             RolloutArgs q = ra;
             q.exchange = reinterpret_cast<unsigned long long*>(&capacity);  // marks the persistent form for the launcher; never dereferenced
             q.capacity_out = &capacity;
+            q.census = e->census.as<int>();
+            q.poll_ticks = std::max(e->poll_ticks, 20000000ll);  // the self-test keeps its 0.2 s whatever bound the hand-over polls were given
             if (launch_rollout(e, R, domains * groups, lds, q, st)) return 1;
-            persistent = domains * groups <= capacity || capacity <= e->num_cu;
+            if (capacity <= 0) {
+                e->persistent_ok = false;  // stays off until hipets_set_persistent(e, 1)
+                persistent = false;
+            } else {
+                // Turns pay off when a CU holds ONE workgroup of this instance (cfg4: 4.51 -> 4.11 ms per rollout, cfg4' 16.4 -> 15.0).
+                // Where two are resident, one launch per step lets the hardware deal 1 250 workgroups to 512 slots as they free up;
+                // fixed turns (3 for some workgroups, 2 for the rest) measured slower there (cfg5: 7.3 vs 6.6 ms).
+                persistent = domains * groups <= capacity || capacity <= e->num_cu;
+            }
         }
         if (!persistent) {  // the persistent form starts from s0 itself and writes every row's total at the end
             hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
@@ -701,9 +751,11 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
                 ra.step_keys = e->step_keys.as<PermKeys>();
             }
             ra.error_flag = e->error_flag;
+            ra.poll_ticks = e->poll_ticks;
             ra.t_begin = 0;
             ra.t_end = H;
             ra.n_logical = domains * groups;
+
             if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;  // cut to the resident capacity by the launcher
         } else if (per_step) {
             for (int t = 0; t < H; ++t) {
@@ -764,6 +816,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     if (B < 1) return fail("bad batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const ModelDev& md = e->md;
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
     if (!md.iid_members && B % md.M != 0 && !(o->mode == HIPETS_MODE_EXACT && o->rows_per_member > 0))  // gaussian_mlp.py:195-200
@@ -904,6 +957,27 @@ int hipets_set_persistent(hipets_engine* e, int32_t on) {
     return 0;
 }
 
+int hipets_set_handover_timeout(hipets_engine* e, double seconds) {
+    if (!e) return fail("null engine");
+    if (!(seconds >= 0.0) || seconds > 60.0) return fail("hand-over timeout %g s outside [0, 60]", seconds);
+    e->poll_ticks = (long long)(seconds * 1.0e8);  // the kernel's wall clock runs at 100 MHz
+    return 0;
+}
+
+int hipets_check_async_error(hipets_engine* e, int32_t* timed_out) {
+    if (!e || !timed_out) return fail("null argument");
+    *timed_out = 0;
+    if (e->error_flag && *e->error_flag) {
+        *e->error_flag = 0;
+        e->persistent_ok = false;  // per-step launches from now on (hipets_set_persistent(e, 1) switches back)
+        *timed_out = 1;
+        g_err = "a persistent DEVICE-mode rollout gave up waiting for rows of another workgroup (its workgroups were not all resident: "
+                "another process or stream held CUs); everything computed from that launch on is invalid -- re-run the call.  "
+                "Persistent launches are now disabled for this engine.";
+    }
+    return 0;
+}
+
 int hipets_set_plan_trace(hipets_engine* e, const hipets_plan_trace* t) {
     if (!e) return fail("null engine");
     e->has_trace = t != nullptr;
@@ -1020,6 +1094,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const CemDev c = make_cem(p, n_env);
     const size_t nd = (size_t)n_env * c.D, npop = (size_t)n_env * c.pop;
     if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure((size_t)n_env * 4 + 16) ||
@@ -1081,6 +1156,7 @@ int hipets_plan_mppi_batched(hipets_engine* e, int32_t pop, int32_t H, int32_t A
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const size_t nd = (size_t)H * A, npop = (size_t)n_env * pop;
     if (e->mu.ensure(n_env * nd * 4) || e->past_action.ensure((size_t)n_env * A * 4) || e->population.ensure(npop * nd * 4) ||
         e->values.ensure(npop * 4))
@@ -1135,6 +1211,7 @@ int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int3
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     // population sizes (:419-431) are known up front: size the workspace for the largest
     std::vector<int> sizes(iters);
     int max_rows = 1;
@@ -1239,6 +1316,7 @@ int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void*
     if (!e || !d) return fail("null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     if (d->latent_size < 1 || d->action_size < 1 || d->belief_size < 1 || d->hidden_size < 1) return fail("bad PlaNet dimensions");
     const void* ptrs[] = {d->w_embed, d->b_embed, d->w_ih, d->b_ih, d->w_hh, d->b_hh, d->w_prior1, d->b_prior1,
                           d->w_prior2, d->b_prior2, d->w_rew1, d->b_rew1, d->w_rew2, d->b_rew2, d->w_rew3, d->b_rew3};
@@ -1320,6 +1398,7 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const long long B = (long long)pop * P;
     if (B > 0x7FFFFFFF / std::max(e->pd.belief, 16)) return fail("batch too large");
     if (e->totals.ensure((size_t)B * 4)) return 1;
@@ -1353,6 +1432,7 @@ int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const f
     if (p->act_dim != e->pd.action) return fail("act_dim %d != model action_size %d", p->act_dim, e->pd.action);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const CemDev c = make_cem(p, 1);
     const size_t nd = (size_t)c.D;
     if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
@@ -1421,6 +1501,18 @@ int hipets_comm_destroy(hipets_engine* e) {
     return 0;
 }
 
+int hipets_comm_info(hipets_engine* e, int32_t* rank, int32_t* world_size) {
+    if (!e) return fail("null engine");
+    int r = e->comm_rank, w = e->comm_world;
+    if (e->comm && g_rccl.CommCount && g_rccl.CommUserRank) {  // what the communicator itself says, not what the caller passed in
+        NCHECK(g_rccl.CommCount(e->comm, &w));
+        NCHECK(g_rccl.CommUserRank(e->comm, &r));
+    }
+    if (rank) *rank = r;
+    if (world_size) *world_size = w;
+    return 0;
+}
+
 int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
                             const float* s0, int32_t P, uint64_t seed, uint64_t plan_id, float* out, void* stream) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
@@ -1430,8 +1522,20 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
     const int world = e->comm_world, rank = e->comm_rank;
     if (p->population_size < world) return fail("population_size %d < world_size %d", p->population_size, world);
+    // Everything that can fail for ONE rank's shard size must fail on EVERY rank, before the first collective (a rank that
+    // returned early would leave its peers blocked in ncclAllGather): the shards hold pop / world or one more candidates, and
+    // DEVICE-mode rollouts of a GaussianMLP ensemble need rows % members == 0 (gaussian_mlp.py:195-200) for both sizes.
+    if (e->plan_mode == HIPETS_MODE_DEVICE && !e->md.iid_members) {
+        const int base = p->population_size / world, extra = p->population_size % world;
+        for (int n : {base, extra ? base + 1 : base})
+            if (((long long)n * P) % e->md.M != 0)
+                return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. A shard of %d candidates x %d "
+                            "particles = %lld rows for %d models (population %d over %d ranks).", n, P, (long long)n * P, e->md.M,
+                            p->population_size, world);
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
+    if (enter_stream(e, st)) return 1;
     const CemDev c = make_cem(p, 1);
     int lo, hi;
     shard_bounds(c.pop, world, rank, &lo, &hi);
@@ -1455,28 +1559,45 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     size_t sched_stride = 0;
     if (plan_prologue(e, s0, 1, local, P, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st, &sched, &sched_stride))
         return 1;
-    for (int i = 0; i < p->num_iterations; ++i) {
-        const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
+    // A rank on which something cannot be enqueued (an allocation, a launch) must NOT leave the loop: its peers are, or will be,
+    // waiting in this and the remaining iterations' collectives.  It keeps contributing (stale) shards to every ncclAllGather and
+    // reports its own error at the end; the peers' plans are then built on garbage, which is why hipets.dist.plan_cem_sharded
+    // agrees on the outcome over all ranks (an all-reduce of the status) before anybody uses a plan.
+    std::string local_err;
+    auto enqueue_local = [&](const int i, const uint64_t sid, float* shard_out) -> int {
         const long long n = (long long)c.pop * c.D;
         hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
                            lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
                            e->population.as<float>());  // identical on every rank: same seed, same counters
         HCHECK(hipGetLastError());
         ro.stream_id = sid;
-        float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
-        if (rollout_impl(e, e->population.as<float>() + (size_t)lo * nd, nullptr, local, c.H, P, &ro, shard_out, stream,
-                         sched ? sched + (size_t)i * sched_stride : nullptr))
-            return 1;
+        return rollout_impl(e, e->population.as<float>() + (size_t)lo * nd, nullptr, local, c.H, P, &ro, shard_out, stream,
+                            sched ? sched + (size_t)i * sched_stride : nullptr);
+    };
+    auto refit_local = [&](const int i) -> int {
         if (world > 1) {
-            NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
             hipLaunchKernelGGL(unpad_shards_kernel, dim3((c.pop + 255) / 256), dim3(256), 0, st, e->gathered.as<float>(), e->values.as<float>(),
                                c.pop, world, width);
             HCHECK(hipGetLastError());
         }
+        int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
         hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
-                           e->best_solution.as<float>(), (int*)nullptr);
+                           e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
+        return trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st);
+    };
+    for (int i = 0; i < p->num_iterations; ++i) {
+        const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
+        float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
+        if (local_err.empty() && enqueue_local(i, sid, shard_out)) local_err = g_err;
+        if (world > 1)  // every rank, every iteration, whatever happened locally
+            NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
+        if (local_err.empty() && refit_local(i)) local_err = g_err;
+    }
+    if (!local_err.empty()) {
+        g_err = local_err;
+        return 1;
     }
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;

@@ -104,7 +104,13 @@ struct RolloutArgs {
     int n_logical;                 // persistent form: logical workgroups (member domain x row group); a launched workgroup serves the
                                    // logical ones wg, wg + gridDim.x, ... one after the other within every step (batches larger than the chip)
     const PermKeys* step_keys;     // DEVICE [H]: round keys of every step's permutation
-    int* error_flag;               // set to 1 when a poll exceeds its spin bound (another workgroup was not resident)
+    int* error_flag;               // HOST-mapped: set to 1 when a poll exceeds its bound (another workgroup was not resident); once it is
+                                   // set every later poll of the launch gives up after <= 64 spins, so a stranded grid drains in
+                                   // milliseconds instead of waiting out the bound at every step and turn
+    long long poll_ticks;          // bound of one hand-over poll in 100 MHz wall-clock ticks (hipets_set_handover_timeout; default 0.2 s)
+    int* census;                   // DEVICE [2], launcher only: when set the launch is the co-residency SELF-TEST of this kernel instance at
+                                   // this grid, not a rollout -- every workgroup arrives at census[0] and waits (bounded by poll_ticks)
+                                   // until all gridDim.x have; those that saw everybody count themselves in census[1]
 };
 
 // D = A(16x4) * B(4x16) + C, exact f32.  Issued through inline asm with the accumulator tied in place
@@ -414,7 +420,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                     return f32x4{yl[0], yl[1], yh[0], yh[1]};
                 });
                 break;
-            case HIPETS_ACT_RELU: store(each([](float x) { return fmaxf(x, 0.0f); })); break;
+            case HIPETS_ACT_RELU: store(each([](float x) { return x < 0.0f ? 0.0f : x; })); break;  // NOT fmaxf: v_max_f32 returns 0 for a NaN input, torch.relu returns NaN
             case HIPETS_ACT_LEAKY_RELU: store(each([slope](float x) { return x > 0.0f ? x : slope * x; })); break;
             case HIPETS_ACT_TANH: store(each([](float x) { return tanhf(x); })); break;
             default: store(each([](float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); })); break;
@@ -1017,6 +1023,23 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
+    if (ra.census) {
+        // Co-residency self-test (launch.hpp / rollout_inst.inc launch_one): the persistent DEVICE form is only correct when every
+        // launched workgroup is resident at once, and the occupancy the host computes (API answer, register and LDS arithmetic) is
+        // an estimate.  Same kernel, same launch configuration, so the same footprint: if all gridDim.x workgroups can meet here,
+        // they can wait for each other's rows.  A workgroup that is not admitted never arrives and the others time out.
+        if (tid == 0) {
+            __hip_atomic_fetch_add(ra.census, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            bool all = true;
+            while (__hip_atomic_load(ra.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+                if (wall_clock64() - t0 > ra.poll_ticks) { all = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (all) __hip_atomic_fetch_add(ra.census + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fast = S::KMODE >= 0 ? S::KMODE == HIPETS_MODE_FAST : ra.mode == HIPETS_MODE_FAST;
@@ -1064,6 +1087,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         }
     }
     const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
+    const bool poll_every = ra.poll_ticks < 1000;  // bounds below 10 us (tests of the time-out path): look at the clock on every spin, not every 64th
     // hand-over table row = NVP pairs of 8-byte granules: the state dims (padded to an even count), then {running total, flag}.
     // exchange item i = (row slot i / NVP, pair i % NVP): items tid + q * kThreads of a thread are the same every step
     constexpr int kG = 2;  // 16-byte pair loads in flight per thread and round (cfg2: 48 rows x 10 pairs = 480 items, one round)
@@ -1481,7 +1505,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                         pair_load_issue(g, src);
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
                         if (g[1] == want && g[3] == want) break;
-                        if ((spins & 63) == 63 && wall_clock64() - t_poll > 20000000ll) {
+                        if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
                             *ra.error_flag = 1;
                             break;
                         }
@@ -1570,9 +1594,11 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                             else if (!soft[q]) ready = false;
                         }
                     if (ready) break;
-                    // a hand-over takes microseconds; 0.2 s without the producer means it is not running at all (the grid is not
-                    // co-resident: another process or stream holds CUs) -- give up loudly instead of spinning on
-                    if ((spins & 63) == 63 && wall_clock64() - t_poll > 20000000ll) {
+                    // a hand-over takes microseconds; 0.2 s (poll_ticks) without the producer means it is not running at all (the grid is
+                    // not co-resident: another process or stream holds CUs) -- give up loudly instead of spinning on; a flag that is
+                    // already up (another workgroup, or an earlier poll, gave up) ends the wait after 64 spins: the results of the
+                    // launch are void anyway and the host re-runs the call (hipets_check_async_error)
+                    if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
                         *ra.error_flag = 1;
                         break;
                     }

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HIPETS_LIB selects another build of the SAME library (kernel-variant experiments under profiles/); there is no fallback
 LIB_PATH = os.environ.get("HIPETS_LIB") or os.path.join(_HERE, "libhipets.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LAYERS = 8
 
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -109,6 +109,8 @@ SYMBOLS = {
     "hipets_device_perms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_set_plan_mode": (C.c_int, [_P, C.c_int32]),
     "hipets_set_persistent": (C.c_int, [_P, C.c_int32]),
+    "hipets_set_handover_timeout": (C.c_int, [_P, C.c_double]),
+    "hipets_check_async_error": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "hipets_set_plan_trace": (C.c_int, [_P, C.POINTER(PlanTrace)]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -130,6 +132,7 @@ SYMBOLS = {
     "hipets_comm_unique_id": (C.c_int, [_P]),
     "hipets_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "hipets_comm_destroy": (C.c_int, [_P]),
+    "hipets_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_plan_cem_sharded": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_planet_set_model": (C.c_int, [_P, C.POINTER(PlanetDesc), _P]),
     "hipets_planet_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PlanetOpts), _P, _P]),

@@ -89,24 +89,55 @@ def init_engine_comm(engine, group=None):
     return engine
 
 
-def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, seed: int = 0, plan_id: int = 0):
-    """``Engine.plan_cem_sharded`` with the failure policy of SURVEY.md section 5: if the engine has no communicator, or RCCL
-    reports an error while the sharded plan is enqueued, warn and plan the WHOLE population on this GPU alone
-    (``hipets_plan_cem``: same sampler streams, so every rank that falls back still returns a valid plan for its
-    observation) instead of failing the control loop.  Returns ``(plan, used_fallback)``."""
+def _worst_status(code: int, group=None) -> int:
+    """Maximum of ``code`` over the ranks (torch.distributed, host side): the ranks agree on the outcome of a sharded plan
+    before any of them acts on it, so that a fallback is taken by ALL of them or none (a lone rank planning on its own while
+    its peers wait in a collective would desynchronise the job)."""
+    if not is_distributed():
+        return code
+    t = torch.tensor([code], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+_OK, _RUNTIME_FAILURE, _REJECTED = 0, 1, 2
+
+
+def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, seed: int = 0, plan_id: int = 0, group=None):
+    """``Engine.plan_cem_sharded`` with the failure policy of SURVEY.md section 5.  The sharded plan runs when the engine has a
+    communicator; afterwards its stream is synchronised, every rank asks its engine whether a rollout was cut short
+    (``check_async_error``) and the ranks AGREE (one host-side all-reduce over ``group`` when torch.distributed is up) on
+    whether the plan stands.  If any rank had a runtime failure -- RCCL reported an error while the plan was enqueued, a
+    persistent rollout timed out, a HIP call or an allocation failed -- every rank drops its communicator, warns, and plans
+    the WHOLE population on its own GPU (``hipets_plan_cem``: same sampler streams, so all ranks still return the same
+    valid plan for the observation) instead of failing the control loop.  Arguments the library rejects (a population the
+    shards cannot hold, a wrong action width: identical on every rank) still raise.  Returns ``(plan, used_fallback)``."""
     import warnings
 
     from ._lib import HipetsError
 
     if engine.comm_world > 1:
+        code, reason, plan, error = _OK, None, None, None
         try:
-            return engine.plan_cem_sharded(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), False
+            plan = engine.plan_cem_sharded(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id)
+            engine.synchronize()
+            if engine.check_async_error():
+                code, reason = _RUNTIME_FAILURE, "a persistent DEVICE-mode rollout timed out"
         except HipetsError as exc:
-            if "RCCL" not in str(exc) and "communicator" not in str(exc):
-                raise
-            warnings.warn(f"hipets: sharded plan failed ({exc}); falling back to a single-GPU plan on rank {engine.comm_rank}")
-            try:
-                engine.comm_destroy()
-            except HipetsError:
-                engine.comm_world, engine.comm_rank = 1, 0
-    return engine.plan_cem(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), engine.comm_world <= 1
+            error, reason = exc, str(exc)
+            runtime = any(k in reason for k in ("RCCL", "communicator", "failed:", "hipMalloc", "launch failed"))
+            code = _RUNTIME_FAILURE if runtime else _REJECTED
+        worst = _worst_status(code, group)
+        if worst == _OK:
+            return plan, False
+        if worst == _REJECTED:
+            raise error if code == _REJECTED else HipetsError("a peer rank rejected the arguments of the sharded plan")
+        warnings.warn(f"hipets: sharded plan failed on rank {engine.comm_rank} or a peer ({reason or 'peer failure'}); "
+                      f"falling back to a single-GPU plan on every rank")
+        try:
+            engine.comm_destroy()
+        except HipetsError:
+            engine.comm_world, engine.comm_rank = 1, 0
+    return engine.plan_cem(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), True

@@ -306,6 +306,22 @@ class Engine:
         """Allow (default) or forbid the persistent one-launch form of DEVICE-mode rollouts (hipets_set_persistent)."""
         _lib.check(self._lib.hipets_set_persistent(self._h, int(bool(on))))
 
+    def synchronize(self):
+        """Wait for everything enqueued on this engine's device (torch.cuda.synchronize)."""
+        torch.cuda.synchronize(self.device)
+
+    def set_handover_timeout(self, seconds: float = 0.2):
+        """Bound of every hand-over poll of the persistent DEVICE-mode form (hipets_set_handover_timeout)."""
+        _lib.check(self._lib.hipets_set_handover_timeout(self._h, float(seconds)))
+
+    def check_async_error(self) -> bool:
+        """True if a persistent DEVICE-mode rollout enqueued on this engine gave up waiting for another workgroup's rows
+        (hipets_check_async_error): call after the results reached the host; on True they are invalid, the engine has
+        switched to per-step launches and the call must be re-run (``TrajectoryOptimizer.optimize`` does)."""
+        flag = C.c_int32(0)
+        _lib.check(self._lib.hipets_check_async_error(self._h, C.byref(flag)))
+        return bool(flag.value)
+
     def set_plan_trace(self, iters: int = 0, max_rows: int = 0, horizon: int = 0, act_dim: int = 0, elite_num: int = 0, n_env: int = 1):
         """Record the following fused plans iteration by iteration (hipets_set_plan_trace); returns the dict of device
         tensors the library writes into.  ``iters=0`` switches recording off.  ``max_rows`` counts the candidates of ALL
@@ -516,6 +532,12 @@ class Engine:
     def comm_destroy(self):
         _lib.check(self._lib.hipets_comm_destroy(self._h))
         self.comm_world, self.comm_rank = 1, 0
+
+    def comm_info(self) -> tuple:
+        """(rank, world size) as the communicator itself reports them (hipets_comm_info)."""
+        r, w = C.c_int32(0), C.c_int32(1)
+        _lib.check(self._lib.hipets_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def plan_cem_sharded(self, p: CemParams, x0, lower, upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0,
                          out: Optional[torch.Tensor] = None) -> torch.Tensor:

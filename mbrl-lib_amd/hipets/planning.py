@@ -51,7 +51,9 @@ class HipTrajectoryEvalFn:
 
     * ``'device'``: the reference's propagation semantics -- ONE balanced random permutation of all
       ``pop * particles`` rows per step (gaussian_mlp.py:203-205), iid eps per row and dim -- with both drawn
-      in-kernel from ``(seed, call counter)`` (a keyed bijection + Philox).  One launch per step.
+      in-kernel from ``(seed, call counter)`` (a keyed bijection + Philox).  ONE persistent launch for the horizon (rows
+      change workgroups through an in-kernel hand-over table); one launch per step where that form does not apply
+      (``Engine.set_persistent(False)``, batches beyond two workgroups per CU) -- same bits either way.
     * ``'fast'``: one launch for the whole horizon; each workgroup (particle p of 16-48 consecutive candidates)
       draws one member per step from a balanced schedule: same marginals, block-wise common random numbers.
     * ``'exact'``: replays the reference's own draws from torch's RNGs in the reference's order (one
@@ -519,11 +521,21 @@ class Optimizer:  # trajectory_opt.py:21-40
         raise NotImplementedError
 
 
+_SEED_COUNTER = [0]
+
+
 def _default_seed(seed: Optional[int]) -> int:
-    """Seed of an optimizer's counter-based streams.  ``None`` draws one from torch's global generator (as the reference
-    keeps advancing that generator): reproducible under ``torch.manual_seed``, different for every optimizer built."""
+    """Seed of an optimizer's counter-based streams.  ``None`` derives one from ``torch.initial_seed()`` (what
+    ``torch.manual_seed`` set) and a per-process construction counter: reproducible under ``torch.manual_seed`` +
+    the same construction order, different for every optimizer built -- WITHOUT consuming torch's global generator (the
+    reference's constructors draw nothing: an extra draw here would shift every later reference-order draw, e.g. the
+    ``sampler='torch'`` / ``mode='exact'`` replays and model initialisation, by one)."""
     if seed is None:
-        seed = int(torch.randint(0, 2**62, (1,)).item())
+        _SEED_COUNTER[0] += 1
+        z = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * _SEED_COUNTER[0]) & (2**64 - 1)  # splitmix64 finaliser
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        seed = z ^ (z >> 31)
     return int(seed) & (2**63 - 1)
 
 
@@ -847,6 +859,9 @@ _TARGET_ALIASES = {
     "mbrl.planning.trajectory_opt.ICEMOptimizer": "hipets.planning.ICEMOptimizer",
     "mbrl.planning.MPPIOptimizer": "hipets.planning.MPPIOptimizer",
     "mbrl.planning.trajectory_opt.MPPIOptimizer": "hipets.planning.MPPIOptimizer",
+    # conf/algorithm/pets.yaml:5 handed to hipets.create_trajectory_optim_agent_for_model unchanged
+    "mbrl.planning.TrajectoryOptimizerAgent": "hipets.planning.TrajectoryOptimizerAgent",
+    "mbrl.planning.trajectory_opt.TrajectoryOptimizerAgent": "hipets.planning.TrajectoryOptimizerAgent",
 }
 
 
@@ -891,6 +906,38 @@ def _instantiate(cfg, **overrides):
     return getattr(importlib.import_module(mod), name)(**kwargs)
 
 
+class _OptimizerSnapshot:
+    """What one ``optimizer.optimize`` call changes besides returning a plan -- the counter-based stream positions
+    (``calls`` of the optimizer and of a hipets objective) and the state that persists across plans (MPPI ``mean``, iCEM
+    ``elite``: SURVEY.md Appendix B6) -- so that a plan whose rollouts were cut short can be re-run as if it never ran."""
+
+    def __init__(self, optimizer, obj_fun):
+        self.optimizer = optimizer
+        self.eval_fn = getattr(obj_fun, "eval_fn", obj_fun)
+        inner = getattr(self.eval_fn, "eval_fn", None)  # dist.ShardedEvalFn wraps the hipets objective
+        self.counters = [o for o in (optimizer, self.eval_fn, inner) if isinstance(getattr(o, "calls", None), int)]
+        self.calls = [o.calls for o in self.counters]
+        self.state = {k: (getattr(optimizer, k).clone() if torch.is_tensor(getattr(optimizer, k)) else getattr(optimizer, k))
+                      for k in ("mean", "elite") if hasattr(optimizer, k)}
+        self.engines = []
+        for o in (optimizer, self.eval_fn, inner):
+            eng = getattr(o, "engine", None)
+            if isinstance(eng, Engine) and eng not in self.engines:
+                self.engines.append(eng)
+
+    def engines_report_timeout(self) -> bool:
+        hit = False
+        for eng in self.engines:
+            hit = eng.check_async_error() or hit
+        return hit
+
+    def restore(self):
+        for o, c in zip(self.counters, self.calls):
+            o.calls = c
+        for k, v in self.state.items():
+            setattr(self.optimizer, k, v.clone() if torch.is_tensor(v) else v)
+
+
 class TrajectoryOptimizer:
     """trajectory_opt.py:490-572: tiles the action bounds over the horizon, instantiates the optimizer,
     warm-starts each call from the previous solution shifted by ``replan_freq``."""
@@ -910,11 +957,26 @@ class TrajectoryOptimizer:
 
     def optimize(self, trajectory_eval_fn: Callable[[torch.Tensor], torch.Tensor],
                  callback: Optional[Callable] = None) -> np.ndarray:
+        snapshot = _OptimizerSnapshot(self.optimizer, trajectory_eval_fn)
         best_solution = self.optimizer.optimize(trajectory_eval_fn, x0=self.previous_solution, callback=callback)
+        plan = best_solution.cpu().numpy()  # the one device->host sync of a plan (:568)
+        # Everything the plan enqueued has executed now.  If a persistent DEVICE-mode rollout inside it gave up waiting for
+        # another workgroup's rows (CUs taken by another process: hipets.h, hipets_check_async_error) the plan was built on
+        # invalid returns: never hand it out.  The engine has switched to per-step launches, which return the same bits the
+        # persistent form would have: put the optimizer back where it was and run the SAME plan again.
+        for _ in range(2):
+            if not snapshot.engines_report_timeout():
+                break
+            snapshot.restore()
+            best_solution = self.optimizer.optimize(trajectory_eval_fn, x0=self.previous_solution, callback=callback)
+            plan = best_solution.cpu().numpy()
+        else:
+            if snapshot.engines_report_timeout():
+                raise HipetsError("DEVICE-mode rollouts keep timing out although persistent launches are off")
         if self.keep_last_solution:  # :563-567
             self.previous_solution = best_solution.roll(-self.replan_freq, dims=0)
             self.previous_solution[-self.replan_freq:] = self.initial_solution[0]
-        return best_solution.cpu().numpy()  # the one device->host sync of a plan (:568)
+        return plan
 
     def reset(self):
         self.previous_solution = self.initial_solution.clone()

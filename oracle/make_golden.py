@@ -314,6 +314,9 @@ FULL_CASES = {
     "cfg4_icem": dict(obs=45, act=17, mkw=dict(ensemble_size=7, hid=200, seed=31, elite=[0, 1, 2, 3, 4], termination="humanoid"),
                       pop=1000, P=20, H=40, iters=5, optimizer="icem", module=7),
     "cfg5_mppi": dict(obs=17, act=6, mkw=dict(ensemble_size=5, hid=200, seed=32), pop=2000, P=20, H=50, iters=5, optimizer="mppi"),
+    # BASELINE.json configs[3] taken literally: Gymnasium Humanoid-v4 (obs 376, 752 output columns) instead of the truncated-obs variant
+    "cfg4p_icem": dict(obs=376, act=17, mkw=dict(ensemble_size=7, hid=200, seed=33, elite=[0, 1, 2, 3, 4], termination="humanoid"),
+                       pop=1000, P=20, H=40, iters=5, optimizer="icem", module=7),
 }
 
 
@@ -370,6 +373,10 @@ def main():
         torch.set_num_threads(8)
         for name in FULL_CASES:
             gen_agent_full(name)
+        return
+    if "--full" in sys.argv:  # one FULL_CASES entry by name (the others' fixtures stay as committed)
+        torch.set_num_threads(8)
+        gen_agent_full(sys.argv[sys.argv.index("--full") + 1])
         return
     torch.set_num_threads(4)
     for name, (obs, act, mkw, pop, P, H) in ROLLOUT_CASES.items():

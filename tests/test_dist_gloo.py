@@ -90,6 +90,12 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
             self.destroyed = True
             self.comm_world, self.comm_rank = 1, 0
 
+        def synchronize(self):
+            pass
+
+        def check_async_error(self):
+            return False
+
     eng = FakeEngine("RCCL error 5 (unhandled system error) at hipets.hip:1200")
     with pytest.warns(UserWarning, match="falling back to a single-GPU plan"):
         plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=3, plan_id=9)
@@ -98,3 +104,15 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
     assert plan[0] == "single-gpu plan" and fell_back
     with pytest.raises(hipets.HipetsError, match="act_dim"):
         hdist.plan_cem_sharded(FakeEngine("act_dim 5 != model act_dim 6"), None, None, None, None, None, 20)
+
+    class TimedOutEngine(FakeEngine):  # the plan was enqueued and "ran", but a persistent rollout inside it gave up
+        def plan_cem_sharded(self, *a, **k):
+            return "sharded plan built on invalid returns"
+
+        def check_async_error(self):
+            return True
+
+    eng = TimedOutEngine("")
+    with pytest.warns(UserWarning, match="timed out"):
+        plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=1, plan_id=2)
+    assert plan == ("single-gpu plan", 1, 2) and fell_back and eng.destroyed

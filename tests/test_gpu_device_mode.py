@@ -10,7 +10,7 @@ import hipets
 from conftest import to_spec
 from oracle import feistel_perm as fp
 from oracle import pets_oracle as po
-from test_gpu_rollout import SIZES, _random_case, assert_returns_close
+from test_gpu_rollout import DEVICE_SIZES, SIZES, _random_case, assert_returns_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -28,7 +28,7 @@ def test_exported_permutations_equal_the_cpu_restatement(engine, B):
         assert np.unique(perms[t]).size == B
 
 
-@pytest.mark.parametrize("case", SIZES[:10], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+@pytest.mark.parametrize("case", DEVICE_SIZES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
 def test_device_mode_replayed_through_oracle(engine, case):
     obs, act, pop, P, H, mkw = case
     om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
@@ -124,7 +124,7 @@ def test_device_mode_rejects_basic_ensemble_member_maps(engine):
 BIG = [(17, 6, 1000, 20, 5, dict(hid=200)), (5, 2, 4000, 5, 4, dict(hid=32)), (17, 6, 650, 20, 3, dict(hid=200))]
 
 
-@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6]] + BIG, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6], SIZES[11]] + BIG, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
 def test_persistent_and_per_step_launches_agree_bitwise(engine, case):
     """DEVICE-mode rollouts run as ONE launch with the rows handed over between workgroups through tagged granules (batches
     with more workgroups than CUs: every launched workgroup serves several logical ones per step); forbidding that (one launch
@@ -209,3 +209,54 @@ def test_fast_mode_statistics_match_reference_semantics_at_cfg2_size(engine):
         c = torch.bincount(sched[t].long(), minlength=5)
         assert c.max() - c.min() <= 1
 
+
+
+def test_timed_out_persistent_rollout_is_reported_and_the_plan_is_rerun(engine):
+    """SURVEY.md 8(b) "never silently approximate": a persistent DEVICE-mode rollout whose hand-over polls give up (here forced:
+    a zero bound, so the first poll that does not find its rows at once quits -- in production: CUs taken by another process)
+    leaves invalid returns.  (1) hipets_check_async_error says so once the results are on the host and the engine falls back to
+    per-step launches; (2) the agent never hands such a plan out: TrajectoryOptimizer.optimize asks after its device-to-host
+    copy, puts the optimizer's counters / persistent state back and runs the SAME plan again -- the action equals, bit for bit,
+    the one an engine that never used the persistent form returns."""
+    obs, act, pop, P, H = 17, 6, 500, 20, 12
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0)
+    spec = to_spec(om, obs, act)
+    engine.set_model(spec)
+    g = torch.Generator().manual_seed(0)
+    actions = (torch.rand(pop, H, act, generator=g) * 2 - 1).to(DEV)
+    s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+
+    def agent():
+        cfg = dict(_target_="hipets.MPPIOptimizer", num_iterations=3, population_size=pop, gamma=0.9, sigma=1.0, beta=0.9, device=DEV,
+                   lower_bound="???", upper_bound="???", seed=5)
+        ag = hipets.TrajectoryOptimizerAgent(cfg, [-1.0] * act, [1.0] * act, planning_horizon=H)
+        ag.set_trajectory_eval_fn(hipets.make_eval_fn(spec, P, engine=engine, seed=3, mode="device"))
+        return ag
+
+    try:
+        engine.set_persistent(False)
+        ref_rollout = engine.rollout(actions, s0, P, mode="device", seed=7, stream_id=1).clone()
+        ref_agent = agent()
+        ref_actions = [ref_agent.act(s0).copy() for _ in range(2)]  # two plans: MPPI's mean persists from one to the next
+        assert not engine.check_async_error()
+        # (1) the raw entry point
+        engine.set_persistent(True)
+        engine.set_handover_timeout(0.0)
+        bad = engine.rollout(actions, s0, P, mode="device", seed=7, stream_id=1)
+        torch.cuda.synchronize()
+        assert engine.check_async_error(), "a zero poll bound did not trip at cfg2 size: the test does not exercise the time-out path"
+        assert not engine.check_async_error()  # reported once; persistent launches are off now
+        again = engine.rollout(actions, s0, P, mode="device", seed=7, stream_id=1)
+        assert torch.equal(again, ref_rollout)
+        del bad
+        # (2) the agent
+        engine.set_persistent(True)
+        ag = agent()
+        got = [ag.act(s0).copy() for _ in range(2)]
+        assert np.array_equal(got[0], ref_actions[0]) and np.array_equal(got[1], ref_actions[1])
+        assert not engine.check_async_error()
+    finally:
+        engine.set_handover_timeout(0.2)
+        engine.set_persistent(True)
+    ok = engine.rollout(actions, s0, P, mode="device", seed=7, stream_id=1)  # the persistent form works again afterwards
+    assert torch.equal(ok, ref_rollout) and not engine.check_async_error()

@@ -158,10 +158,13 @@ def test_fused_mppi_plan_cfg5_replayed_through_oracle(engine, mode):
 
 
 @pytest.mark.parametrize("mode", ["device", "fast"])
-def test_fused_icem_plan_cfg4_replayed_through_oracle(engine, mode):
+@pytest.mark.parametrize("case_name", ["cfg4_icem", "cfg4p_icem"])
+def test_fused_icem_plan_cfg4_replayed_through_oracle(engine, mode, case_name):
     """cfg4: 7 members / 5 elites, pop 1000 decaying by 1.3 rounded up to multiples of 7, 35 kept elites, H 40, A 17; the second
-    plan shifts the kept elites (:450-462) and its last iteration evaluates the extra `mu` row (B = (n + 1) P, Appendix B7)."""
-    c, om, s0 = make_case("cfg4_icem")
+    plan shifts the kept elites (:450-462) and its last iteration evaluates the extra `mu` row (B = (n + 1) P, Appendix B7).
+    cfg4_icem = the truncated-observation Humanoid (obs 45); cfg4p_icem = BASELINE configs[3] taken literally (Gymnasium
+    Humanoid-v4: obs 376, 752 output columns; DEVICE mode serves its 1 300 one-tile logical workgroups in turns)."""
+    c, om, s0 = make_case(case_name)
     obs, act, P, H, pop, iters, module = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"], c["module"]
     fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=7, mode=mode)
     lower, upper = -torch.ones(H, act), torch.ones(H, act)
