@@ -471,9 +471,19 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         lms[l].woff = woff;
         lms[l].boff = boff;
         lms[l].tail_steps = (Ks[l] - (lms[l].Kp - 16) + 3) / 4;
+        lms[l].woff_pairs = -1;
+        lms[l].boff_pairs = 0;
+        lms[l].pad2_ = 0;
         woff += (long long)lms[l].Kp * lms[l].Np;
         boff += lms[l].Np;
         maxK = std::max(maxK, std::max(lms[l].Kp, lms[l].Np));
+    }
+    if (!d->deterministic) {  // second pack of the mean / logvar head in "head pair" column order (rollout.hpp head_pair_col, KSpec::FUSE)
+        LayerMeta& out = lms[d->n_layers - 1];
+        out.woff_pairs = woff;
+        out.boff_pairs = boff;
+        woff += (long long)out.Kp * out.Np;  // ceil(out_dim / 8) column tiles == Np / 16: the pair order never needs more tiles
+        boff += out.Np;
     }
     md.precision = d->precision;
     if (d->precision != HIPETS_PREC_F32 && d->precision != HIPETS_PREC_BF16X3) return fail("unknown precision %d", d->precision);
@@ -531,8 +541,18 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         const int nb = md.M * lms[l].Np;
         hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
                            reinterpret_cast<const float*>(d->biases[l]), e->members.as<int>(), md.M, Ns[l], lms[l].Np, md.bmember,
-                           lms[l].boff, l < d->n_layers - 1 ? 1 : 0);
+                           lms[l].boff, l < d->n_layers - 1 ? 1 : 0, 0);
         HCHECK(hipGetLastError());
+        if (lms[l].woff_pairs >= 0) {
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e->wpack.as<float>(),
+                               reinterpret_cast<const float*>(d->weights[l]), e->members.as<int>(), md.M, Ks[l], Ns[l], lms[l].Kp,
+                               lms[l].Np, md.wmember, lms[l].woff_pairs, 2, 0, d->out_dim);
+            HCHECK(hipGetLastError());
+            hipLaunchKernelGGL(pack_bias_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, e->bpack.as<float>(),
+                               reinterpret_cast<const float*>(d->biases[l]), e->members.as<int>(), md.M, Ns[l], lms[l].Np, md.bmember,
+                               lms[l].boff_pairs, 2, d->out_dim);
+            HCHECK(hipGetLastError());
+        }
     }
     if (d->normalizer != HIPETS_NORM_NONE) {
         if (e->norm_mean.ensure((size_t)d->in_dim * 8) || e->norm_std.ensure((size_t)d->in_dim * 8)) return 1;

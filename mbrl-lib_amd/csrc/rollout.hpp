@@ -35,7 +35,23 @@ struct LayerMeta {
     int Kp32;            // K padded to a multiple of 32 (one v_mfma_f32_16x16x32_bf16 k-chunk)
     int pad_;
     long long woff3;     // 16-byte-unit offset of the layer's packed bf16 planes inside a member block
+    // output layer of a stochastic model only: a SECOND pack of its weights / biases with the columns in "head pair" order
+    // (head_pair_col below) for the kernel instances that sample straight from the accumulators (KSpec::FUSE); -1 = none
+    long long woff_pairs;
+    int boff_pairs;
+    int pad2_;
 };
+
+// "Head pair" column order of the output layer (mean_and_logvar, gaussian_mlp.py:107-112): packed column p = 16 c + 4 g + i
+// holds, for the output dim d = 8 c + 2 g + (i & 1), its mean (i < 2) or its log-variance (i >= 2).  Formed transposed, the
+// product leaves lane group g of column tile c with {mean d, mean d+1, logvar d, logvar d+1} of one batch row in ONE
+// accumulator: everything the sampling of those two dims needs (model.py:471-473), no LDS round trip.  -1 = zero padding.
+__host__ __device__ __forceinline__ int head_pair_col(int p, int out_dim) {
+    const int c = p >> 4, g = (p >> 2) & 3, i = p & 3;
+    const int d = 8 * c + 2 * g + (i & 1);
+    if (d >= out_dim) return -1;
+    return i < 2 ? d : out_dim + d;
+}
 
 struct Extras {  // up to kMaxExtras leftover (column tile, row tile) units of one wave
     int c0, c1, c2, c3, r0, r1, r2, r3;
@@ -210,19 +226,71 @@ __device__ __forceinline__ void prefetch_issue(const NextOp& n, const int lane, 
     __builtin_amdgcn_sched_barrier(0);  // keep the requests HERE (the scheduler would sink them to their first use)
 }
 
+// Minimum waves per SIMD the register allocation must leave room for (= workgroups of 4 waves per CU).  R <= 2 keeps two
+// workgroups per CU resident (their barrier / latency phases overlap); R = 3, 4 need the registers.
+#ifndef HIPETS_MINWAVES_R1
+#define HIPETS_MINWAVES_R1 2
+#endif
+#ifndef HIPETS_MINWAVES_R2
+#define HIPETS_MINWAVES_R2 2
+#endif
+template <int R> struct MinWavesOf { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
+
+struct NoTail {};  // wave_gemm's TL: the ordinary epilogue (activation, store as the next op's LDS image)
+// A fused tail = three stages over the accumulators (units) a wave finished: prep(slot, c, r) for EVERY unit first -- it only
+// loads (LDS) what the unit will need into its slot, so the round trips of all units overlap --, then unit(slot, acc, c, r)
+// for every unit (arithmetic + stores), then finish() once per wave.
+struct FusedSlot {  // what one unit's lane reads from LDS (rollout_kernel, KSpec::FUSE)
+    float mxA, mxB, mnA, mnB, pA, pB;
+    double nmA, nmB, nsA, nsB;
+    int rid, ndA, ndB;
+};
+template <class P, class F, class G>
+struct TailStages {
+    P prep;
+    F unit;
+    G finish;
+};
+template <class P, class F, class G>
+__device__ __forceinline__ TailStages<P, F, G> make_tail(P p, F f, G g) { return TailStages<P, F, G>{p, f, g}; }
+
 // ACT >= 0: the activation is a compile-time fact (one epilogue in the code); ACT < 0: `act` selects it at run time.
 // PRE: chunk 0's weight fragments and the biases are already in `pre` (prefetch_issue by the previous op); after the k loop
 // the next op's are requested into `pre` again (`nxt`).
-template <int R, int CT, int EX, int ACT, bool PRE = false>
-__device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld,
-                                          const float* __restrict__ W, const float* __restrict__ bias, const int KC,
+// TL != NoTail: instead of the epilogue every finished accumulator is handed to (*tl)(acc, column tile, row tile) -- the fused
+// per-step tail of the output layer (KSpec::FUSE: sampling, next state, reward, next input straight from the registers).
+// LD > 0: the LDS row stride is a compile-time fact (shape-specialised instances): the A-fragment reads of the R row tiles become
+// ONE base register + immediate offsets (ds_read_b128 ... offset:r * 16 * LD * 4), no per-row address arithmetic in the k loop.
+#ifndef HIPETS_BUFFER_LOADS
+#define HIPETS_BUFFER_LOADS 1  // weight fragments through buffer_load ... s_off offen: the chunk offset rides in an SGPR
+#endif
+#ifndef HIPETS_KSTEP_NOP
+#define HIPETS_KSTEP_NOP 1  // s_nop 1 in front of every k-step (hazard guard, see kstep below)
+#endif
+// SPL: every unit sums its even and its odd k-steps in two accumulators and adds them at the end -- the order a wave whose whole
+// share is ONE unit uses anyway (hazard (2) below).  The OUTPUT layer runs with SPL in every instance: its columns are dealt to
+// the waves differently by the natural and the head-pair packs, and with SPL a column's sum does not depend on whether its wave
+// holds one unit or several -- shape-specialised and generic instances keep returning the same bits.
+// KCS > 0: the number of k chunks is a compile-time fact (ops whose K is the hidden width of a shape-specialised instance): the
+// k loop is fully unrolled -- straight-line code, no loop control, no accumulator copies where blocks meet.
+#ifndef HIPETS_UNROLL_K
+#define HIPETS_UNROLL_K 1
+#endif
+#ifndef HIPETS_INTERLEAVE
+#define HIPETS_INTERLEAVE 1  // the next chunk's fragment loads inside the MFMAs' shadows (compute_il in wave_gemm)
+#endif
+template <int R, int CT, int EX, int ACT, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1>
+__device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld_rt,
+                                          const float* __restrict__ W, const float* __restrict__ bias, const int KC_rt,
                                           const int tail_steps, const int c_first, const Extras ex,
                                           const bool apply_act, const int act, const float slope, const int lane,
-                                          Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr) {
+                                          Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr) {
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
     f32x4 acc[CTn][R];
     f32x4 accx[EXn];
+    const int ld = LD > 0 ? LD : ld_rt;
+    const int KC = KCS > 0 ? KCS : KC_rt;
 
     const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
     const int exr[kMaxExtras] = {ex.r0, ex.r1, ex.r2, ex.r3};
@@ -253,12 +321,36 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
         for (int e = 0; e < EX; ++e) bvx[e] = *reinterpret_cast<const f32x4*>(bias + exc[e] * 16 + 4 * (lane >> 4));
     }
+#if HIPETS_BUFFER_LOADS
+    // The weight block of this op as a raw buffer (base = W, wave-uniform): a fragment load is buffer_load_dwordx4 v, v_off, s[rsrc],
+    // s_chunk offen -- the loop-invariant per-lane offset in a VGPR, the chunk offset (kk KiB) in an SGPR, NO address VALU work in
+    // the k loop (fp32 MFMAs and VALU instructions exclude each other on a SIMD: every v_lshl_add_u64 there is MFMA-pipe idle time)
+    // (W is wave-uniform by construction -- member and layer are -- but parts of it came through LDS, which the compiler's divergence
+    // analysis cannot see: without the readfirstlane it wraps every buffer_load in a waterfall loop)
+    const unsigned long long wbits = reinterpret_cast<unsigned long long>(W);
+    const unsigned long long wuni = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wbits >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wbits);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(wuni), 0, 0x7FFFFFFF, 0x00020000);
+    auto wload = [&](const unsigned voff, const int kk) __attribute__((always_inline)) {
+        const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)voff, kk * 1024, 0);
+        f32x4 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    };
+#endif
     auto load = [&](GemmFrags<R, CT, EX>& f, const int kk) __attribute__((always_inline)) {
+#if HIPETS_BUFFER_LOADS
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) f.b[ct] = wload(woff[ct], kk);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) f.bx[e] = wload(wxoff[e], kk);
+#else
         const char* Wk = Wb + (size_t)kk * 1024;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) f.b[ct] = *reinterpret_cast<const f32x4*>(Wk + woff[ct]);
 #pragma unroll
         for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(Wk + wxoff[e]);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + kk * 16);
 #pragma unroll
@@ -269,13 +361,32 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // previous MFMA's D as C back-to-back (issue interval 32 < dependent latency 40 cycles) reads a stale C on
     // VGPR accumulators -> a wave whose whole share is ONE unit alternates two accumulators (even / odd k-steps).
     constexpr bool kSplit = (CT * R + EX) == 1;
+    constexpr bool kSplitAll = SPL && !kSplit;
     f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acco[CTn][R], accxo[EXn];  // kSplitAll: the odd k-steps of every unit
+#pragma unroll
+    for (int ct = 0; ct < CTn; ++ct)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acco[ct][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < EXn; ++e) accxo[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto kstep = [&](const GemmFrags<R, CT, EX>& f, const int s) __attribute__((always_inline)) {
+#if HIPETS_KSTEP_NOP
         asm volatile("s_nop 1");
+#else
+        if (s == 0) asm volatile("s_nop 1");  // experiment: the guard once per chunk (after the fragment loads' register writes) only
+#endif
         if constexpr (kSplit) {
             f32x4& dst = (s & 1) ? acc_odd : (CT ? acc[0][0] : accx[0]);
             if constexpr (CT) mfma16x16x4(f.b[0][s], f.a[0][s], dst);
             else mfma16x16x4(f.bx[0][s], f.ax[0][s], dst);
+        } else if constexpr (kSplitAll) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < R; ++r) mfma16x16x4(f.b[ct][s], f.a[r][s], (s & 1) ? acco[ct][r] : acc[ct][r]);
+#pragma unroll
+            for (int e = 0; e < EX; ++e) mfma16x16x4(f.bx[e][s], f.ax[e][s], (s & 1) ? accxo[e] : accx[e]);
         } else {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -288,6 +399,76 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     auto compute = [&](const GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) kstep(f, s);
+    };
+    // Interleaved form of "load the next chunk, then compute this one" (HIPETS_INTERLEAVE): the kNL fragment loads of chunk
+    // kk_next are issued ONE AT A TIME, evenly spread behind the MFMAs of the current chunk, instead of as a clump in front of it.
+    // Measured stand-alone (profiles/microbench/kloop_probe.hip, this wave's 3 x 3 + 1 tiling, 220 workgroups): a VMEM / LDS
+    // instruction issued while no MFMA is executing costs ~12 cycles of matrix-pipe idle time (8 per 40 MFMAs: 34.46 cycles per
+    // MFMA); issued inside an MFMA's 32-cycle shadow it is free (32.98).  Weight fragments first: they have the L2 round trip
+    // ahead of them and are needed >= 30 MFMAs (~1 000 cycles) later; the LDS fragments follow in the order the next chunk's first
+    // MFMAs consume them.  sched_barrier(0) on both sides pins each load where it is written.
+    constexpr bool kIL = HIPETS_INTERLEAVE && LD > 0;  // shape-specialised instances only: in the generic ones (every shape x activation in
+                                                        // one kernel, at the 256-VGPR limit) the longer live ranges spill 16-20 VGPRs to scratch
+    constexpr int kNU = CT * R + EX;                              // MFMA units of this wave
+    constexpr int kNL = CT + EX + (CT > 0 ? R : 0) + EX;          // fragment loads per chunk
+    static_assert(4 * kNU >= kNL + 1, "every load needs its own slot behind an MFMA");
+    auto load_one = [&](GemmFrags<R, CT, EX>& g, const int kk, const int i) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#if HIPETS_BUFFER_LOADS
+        if (i < CT) g.b[i < CT ? i : 0] = wload(woff[i < CT ? i : 0], kk);
+        else if (i < CT + EX) g.bx[i - CT] = wload(wxoff[i - CT], kk);
+#else
+        if (i < CT) g.b[i < CT ? i : 0] = *reinterpret_cast<const f32x4*>(Wb + (size_t)kk * 1024 + woff[i < CT ? i : 0]);
+        else if (i < CT + EX) g.bx[i - CT] = *reinterpret_cast<const f32x4*>(Wb + (size_t)kk * 1024 + wxoff[i - CT]);
+#endif
+        else if (CT > 0 && i < CT + EX + R) g.a[i - CT - EX] = *reinterpret_cast<const f32x4*>(ap + (i - CT - EX) * 16 * ld + kk * 16);
+        else {
+            const int e = i - CT - EX - (CT > 0 ? R : 0);
+            g.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + kk * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_unit = [&](const GemmFrags<R, CT, EX>& f, const int s, const int u) __attribute__((always_inline)) {
+        if constexpr (kSplit) {
+            f32x4& dst = (s & 1) ? acc_odd : (CT ? acc[0][0] : accx[0]);
+            if constexpr (CT) mfma16x16x4(f.b[0][s], f.a[0][s], dst);
+            else mfma16x16x4(f.bx[0][s], f.ax[0][s], dst);
+        } else if (u < CT * R) {
+            const int ct = u / R, r = u - ct * R;
+            if constexpr (kSplitAll) mfma16x16x4(f.b[ct][s], f.a[r][s], (s & 1) ? acco[ct][r] : acc[ct][r]);
+            else mfma16x16x4(f.b[ct][s], f.a[r][s], acc[ct][r]);
+        } else {
+            const int e = u - CT * R;
+            if constexpr (kSplitAll) mfma16x16x4(f.bx[e][s], f.ax[e][s], (s & 1) ? accxo[e] : accx[e]);
+            else mfma16x16x4(f.bx[e][s], f.ax[e][s], accx[e]);
+        }
+    };
+    // after MFMA number m1 (1-based) of the chunk: the loads whose slot this is.  Load j goes behind MFMA (j + 1) * total / (kNL + 1):
+    // evenly spread, the last one still several MFMAs ahead of the chunk's end (the next chunk's first MFMAs want its data).
+    // Plain nested loops with compile-time bounds and an explicit `#pragma unroll` each: every array index must be a constant
+    // after unrolling (a dynamically indexed fragment array is demoted to scratch memory -- measured: 28 ms per rollout).
+    auto loads_behind = [&](GemmFrags<R, CT, EX>& g, const int kk_next, const int m1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kNL; ++j)
+            if (((j + 1) * 4 * kNU) / (kNL + 1) == m1) load_one(g, kk_next, j);
+    };
+    auto compute_il = [&](const GemmFrags<R, CT, EX>& f, GemmFrags<R, CT, EX>& g, const int kk_next) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            asm volatile("s_nop 1");  // hazard guard of kstep above
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    mfma_unit(f, ks, ct * R + r);
+                    loads_behind(g, kk_next, ks * kNU + ct * R + r + 1);
+                }
+#pragma unroll
+            for (int e = 0; e < EX; ++e) {
+                mfma_unit(f, ks, CT * R + e);
+                loads_behind(g, kk_next, ks * kNU + CT * R + e + 1);
+            }
+        }
     };
     // The compiler models an asm MFMA as an ordinary instruction whose result is ready immediately, so any VALU
     // copy of an accumulator it places right behind one (phi copies where control flow merges) would read the
@@ -303,6 +484,14 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
         for (int e = 0; e < EX; ++e) asm volatile("" : "+v"(accx[e]));
         asm volatile("" : "+v"(acc_odd));
+        if constexpr (kSplitAll) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("" : "+v"(acco[ct][r]));
+#pragma unroll
+            for (int e = 0; e < EX; ++e) asm volatile("" : "+v"(accxo[e]));
+        }
     };
     // last chunk: only the k-steps that hold real (non-padding) weights, e.g. 2 of 4 for K = 200
     auto compute_tail = [&](const GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {
@@ -339,38 +528,107 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
     for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
     prof.mark(14);
-    const int last = KC - 1;
-    int kk = 0;
-    for (; kk + 2 < KC; kk += 2) {  // chunks kk, kk+1 are not the last one
-        load(f1, kk + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(f0, kk + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(f1);
-        __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KCS > 0) {
+        constexpr int kEnd = KCS >= 2 ? ((KCS - 1) / 2) * 2 : 0;  // the loop below leaves kk at the smallest even number >= KCS - 2
+#pragma unroll
+        for (int kk = 0; kk + 2 < KCS; kk += 2) {
+            if constexpr (kIL) {
+                compute_il(f0, f1, kk + 1);
+                compute_il(f1, f0, kk + 2);
+            } else {
+                load(f1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(f0, kk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (kEnd + 1 < KCS) {
+            if constexpr (kIL) {
+                compute_il(f0, f1, kEnd + 1);
+            } else {
+                load(f1, kEnd + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            compute_tail(f1);
+        } else {
+            compute_tail(f0);
+        }
+    } else {
+        int kk = 0;
+        for (; kk + 2 < KC; kk += 2) {  // chunks kk, kk+1 are not the last one
+            if constexpr (kIL) {
+                compute_il(f0, f1, kk + 1);
+                compute_il(f1, f0, kk + 2);
+            } else {
+                load(f1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(f0, kk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (kk > 0) drain_all();
+        if (kk + 1 < KC) {  // two chunks left: kk (full) and kk+1 (tail)
+            if constexpr (kIL) {
+                compute_il(f0, f1, kk + 1);
+            } else {
+                load(f1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(f0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            compute_tail(f1);
+        } else {  // one chunk left
+            compute_tail(f0);
+        }
     }
-    if (kk > 0) drain_all();
-    if (kk + 1 < KC) {  // two chunks left: kk (full) and kk+1 (tail)
-        load(f1, kk + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_tail(f1);
-    } else {  // one chunk left
-        compute_tail(f0);
+    FusedSlot slots[CT * R + EX > 0 ? CT * R + EX : 1];
+    if constexpr (!std::is_same<TL, NoTail>::value) {  // the tail's LDS loads of ALL units, in flight while the matrix pipe drains
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < R; ++r) tl->prep(slots[ct * R + r], c_first + kWaves * ct, r);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) tl->prep(slots[CT * R + e], exc[e], exr[e]);
     }
-    (void)last;
     if constexpr (kSplit) {
         mfma_drain();
         if constexpr (CT) acc[0][0] += acc_odd;
         else accx[0] += acc_odd;
     }
+    if constexpr (kSplitAll) {
+        drain_all();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[ct][r] += acco[ct][r];
+#pragma unroll
+        for (int e = 0; e < EX; ++e) accx[e] += accxo[e];
+    }
     mfma_drain();
     __builtin_amdgcn_sched_barrier(0);
     prof.mark(11);
     if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
+    if constexpr (!std::is_same<TL, NoTail>::value) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < R; ++r) tl->unit(slots[ct * R + r], acc[ct][r], c_first + kWaves * ct, r);
+#pragma unroll
+        for (int e = 0; e < EX; ++e) tl->unit(slots[CT * R + e], accx[e], exc[e], exr[e]);
+        tl->finish();
+        prof.mark(9);  // the fused tail is booked as the "sample" phase
+        return;
+    }
 
     // epilogue: D[row = 4*(lane>>4)+i][col = lane&15] -> bias, activation, next layer's A image.
     // The activation switch is hoisted OUT of the element loops: one compact straight-line body per
@@ -429,18 +687,24 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     prof.mark(13);
 }
 
-template <int R, int CT, int ACT>
+template <int R, int CT, int ACT, bool SPL = false>
 __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* out, int ld, const float* W,
                                              const float* bias, int KC, int tail_steps, int c_first, const Extras ex,
                                              bool apply_act, int act, float slope, int lane, Prof& prof) {
+    // a wave holds at most ceil(3 R / 4) leftover units (C % 4 <= 3 leftover column tiles x R row tiles dealt to 4 waves): only those
+    // counts are instantiated (every instance adds to the kernel's register maximum, and the generic kernels sit at the limit)
+    constexpr int kMaxEx = (3 * R + kWaves - 1) / kWaves;
     switch (nex) {
         case 0:
-            if constexpr (CT > 0) wave_gemm<R, CT, 0, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
+            if constexpr (CT > 0) wave_gemm<R, CT, 0, ACT, false, NoTail, -1, SPL>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
             break;
-        case 1: wave_gemm<R, CT, 1, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        case 2: wave_gemm<R, CT, 2, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        case 3: wave_gemm<R, CT, 3, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
-        default: wave_gemm<R, CT, 4, ACT>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 1: wave_gemm<R, CT, 1, ACT, false, NoTail, -1, SPL>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof); break;
+        case 2:
+            if constexpr (kMaxEx >= 2) wave_gemm<R, CT, 2, ACT, false, NoTail, -1, SPL>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
+            break;
+        default:
+            if constexpr (kMaxEx >= 3) wave_gemm<R, CT, 3, ACT, false, NoTail, -1, SPL>(in, out, ld, W, bias, KC, tail_steps, c_first, ex, apply_act, act, slope, lane, prof);
+            break;
     }
 }
 
@@ -449,10 +713,11 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 // CS >= 0: the number of column tiles is a compile-time fact (shape-specialised kernels): every wave's (CT, EX) follows
 // from it and the wave index through ONE branch, and only the two wave_gemm instances the shape needs are compiled;
 // CS < 0: it is read from the layer table and dispatched through the (full, nex) switches.
-template <int R, int ACT = -1, int CS = -1, bool PRE = false>
+template <int R, int ACT = -1, int CS = -1, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
-                                          const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr) {
+                                          const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr) {
+    static_assert(std::is_same<TL, NoTail>::value || CS >= 0, "a fused tail needs a shape-specialised op");
     const int KC = lm.Kp / kKChunk;
     // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
     // fragment registers must fit the 256 VGPRs two waves per SIMD leave each wave)
@@ -468,21 +733,21 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         constexpr int last = full - passes * kMaxCT;                      // 0 .. kMaxCT column tiles ride with the extras
 #pragma unroll
         for (int p = 0; p < passes; ++p)
-            wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof);
+            wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl);
         const int c_first = wave + kWaves * kMaxCT * passes;
         // the nu leftover units are dealt round-robin: waves below nu % kWaves hold one more than the others
         constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
         static_assert(!PRE || passes == 0, "cross-layer prefetch needs the op to fit one wave_gemm per wave");
         if constexpr (lo == hi) {
             if constexpr (last > 0 || lo > 0)
-                wave_gemm<R, last, lo, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
+                wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
             else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);  // nothing to compute here: still fetch for the next op
         } else {
             if (wave < nu % kWaves) {
-                wave_gemm<R, last, hi, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
+                wave_gemm<R, last, hi, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
             } else {
                 if constexpr (last > 0 || lo > 0)
-                    wave_gemm<R, last, lo, ACT, PRE>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt);
+                    wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
                 else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
             }
         }
@@ -499,17 +764,18 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         const int nex = wave < nu ? (nu - wave + kWaves - 1) / kWaves : 0;  // <= kMaxExtras since rem < kWaves, R <= 4
         int done = 0;
         while (full - done > kMaxCT) {
-            wave_gemm<R, kMaxCT, 0, ACT>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
+            wave_gemm<R, kMaxCT, 0, ACT, false, NoTail, -1, SPL>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * done, ex, apply_act, activation, slope, lane, prof);
             done += kMaxCT;
         }
         const int c_first = wave + kWaves * done;
         switch (full - done) {
-            case 0: wave_gemm_ex<R, 0, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-            case 1: wave_gemm_ex<R, 1, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
-            case 2: wave_gemm_ex<R, 2, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            case 0: wave_gemm_ex<R, 0, ACT, SPL>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            case 1: wave_gemm_ex<R, 1, ACT, SPL>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
+            case 2: wave_gemm_ex<R, 2, ACT, SPL>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof); break;
             default:
-                if constexpr (kMaxCT >= 3)
-                    wave_gemm_ex<R, 3, ACT>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
+                // (SPL ops have at most 8 column tiles, i.e. at most 2 strided tiles per wave: mlp_layer)
+                if constexpr (kMaxCT >= 3 && !SPL)
+                    wave_gemm_ex<R, 3, ACT, SPL>(nex, in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof);
                 break;
         }
     }
@@ -742,11 +1008,36 @@ __device__ __forceinline__ void linear_op_b3(const uint4* W3, const float* bias,
 // per-member logvar bounds) is compiled out.  The host picks an instance only when the model and the call match ALL of its
 // facts (launch.hpp select_*); anything else runs the generic instance.  Same arithmetic, instruction for instruction, in
 // the parts both execute: tests compare the two bit for bit.
-template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1, int PREC_ = 0>
+// LDS row stride the host derives for a model whose widest layer has `tiles` column tiles (hipets_set_model: >= the widest
+// activation, == 8 mod 64); a shape-specialised instance runs only when the model's stride is this one (launch: lean_shape_ok)
+// Output layers of up to this many column tiles sum every unit's even / odd k-steps separately (wave_gemm SPL) and, in the
+// shape-specialised fp32 instances, feed the fused tail (KSpec::FUSE).  Wider ones (cfg4': 47) keep the plain order: a wave's share
+// is a dozen units there, and twice the accumulators (or a dozen inlined tails) do not fit the register file.
+constexpr int kSplMaxTiles = 8;
+
+constexpr int lean_ld(int hidc, int outc) {
+    int m = (hidc > outc ? hidc : outc) * 16;
+    while (m % 64 != 8) m += 4;
+    return m;
+}
+
+template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1, int PREC_ = 0,
+          int FUSE_ = 0>
 struct KSpec {
+    static constexpr int LD = (HIDC_ >= 0 && PREC_ == HIPETS_PREC_F32) ? lean_ld(HIDC_, OUTC_) : -1;  // compile-time LDS row stride (fp32 lean instances)
     static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
     static constexpr int PREC = PREC_;  // HIPETS_PREC_F32 (fp32 MFMA) or HIPETS_PREC_BF16X3 (lean instances only)
     static constexpr bool LEAN = HIDC_ >= 0;
+    // FUSE (lean fp32 instances): the output layer runs on the "head pair" pack and its accumulators go straight into the
+    // step's tail -- sampling, delta, next state, hand-over publication, reward / termination / totals and the next step's
+    // normalised model input happen in registers in the output layer's own barrier interval (5 barriers per step instead
+    // of 7, no LDS round trip of the 2 x out_dim outputs).  Needs reward / termination forms that read state dims 0..3 only.
+    // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
+    static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && OUTC_ <= kSplMaxTiles;
+    static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE) &&
+                            (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID)),
+                  "fused tail: the reward / termination lane sees dims 0..3 of its row");
+    static_assert(!FUSE || (NORM_ == HIPETS_NORM_F64 && OBSP_ == HIPETS_OBS_NONE), "fused tail: f64 normaliser, no obs preprocessing");
 };
 
 // can an op with CS column tiles take part in the cross-layer prefetch? (one wave_gemm per wave, see linear_op)
@@ -811,11 +1102,31 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
     const float* W = md.w + (size_t)member * md.wmember + lm.woff;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
     if constexpr (S::LEAN) {
-        if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
-        else linear_op<R, S::ACT, S::OUTC>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
+        // ops fed by a hidden layer have K = hid: HIDC chunks, a compile-time count (the input layer's K is the model's input width)
+        // Unrolled only where the register file is not the constraint (R >= 3: one workgroup per CU, 512 registers per lane).  At R = 2
+        // (two workgroups per CU, 256-register cap) the allocator splits accumulator live ranges inside the unrolled stream and
+        // puts v_mov copies straight behind asm MFMAs -- which it believes complete at once (wave_gemm, "drain_all") -- and the
+        // interleaved + unrolled build returned wrong sums (caught by the cfg5 parity tests); R = 1 measured 1 % slower unrolled.
+        constexpr int kHidChunks = (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1;
+        if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        else linear_op<R, S::ACT, S::OUTC, false, NoTail, S::LD, (S::OUTC <= kSplMaxTiles), kHidChunks>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
     } else {
-        linear_op<R, S::ACT>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
+        // the output layer of up to kSplMaxTiles column tiles: SPL (the SAME rule in the shape-specialised branch above)
+        if (l == md.n_layers - 1 && lm.Np / kTile <= kSplMaxTiles)
+            linear_op<R, S::ACT, -1, false, NoTail, -1, true>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
+        else linear_op<R, S::ACT>(W, bias, lm, md.ld, l < md.n_layers - 1, md.activation, md.slope, in, out, wave, lane, prof);
     }
+}
+
+// The OUTPUT layer of a KSpec::FUSE instance: the "head pair" pack, accumulators handed to `tl` (no LDS image of the outputs)
+template <int R, class S, class TL>
+__device__ __forceinline__ void mlp_output_layer_fused(const ModelDev& md, const LayerMeta* lmeta, const int member, const float* in,
+                                                       const int wave, const int lane, Prof& prof, const TL& tl) {
+    const LayerMeta lm = lmeta[md.n_layers - 1];
+    const float* W = md.w + (size_t)member * md.wmember + lm.woff_pairs;
+    const float* bias = md.b + (size_t)member * md.bmember + lm.boff_pairs;
+    linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, true, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
 }
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
@@ -924,6 +1235,7 @@ struct RolloutSmem {
     int* sched;      // [H] member slot of this workgroup per step (FAST)
     LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
     long long* prof;   // [kWaves][16] phase-cycle accumulators (profiling aid)
+    float* dump;     // [4] sink of the fused tail's masked-off LDS stores (branch-free: an inactive lane stores here)
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
@@ -942,6 +1254,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += align16((size_t)horizon * 4);
     n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
     n += align16((size_t)kWaves * 16 * 8);
+    n += 16;  // dump slot
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
@@ -955,15 +1268,7 @@ __device__ __forceinline__ float softplus_fast(float x) {
     return x > 20.0f ? x : y;
 }
 
-// Minimum waves per SIMD the register allocation must leave room for (= workgroups of 4 waves per CU).  R <= 2 keeps two
-// workgroups per CU resident (their barrier / latency phases overlap); R = 3, 4 need the registers.
-#ifndef HIPETS_MINWAVES_R1
-#define HIPETS_MINWAVES_R1 2
-#endif
-#ifndef HIPETS_MINWAVES_R2
-#define HIPETS_MINWAVES_R2 2
-#endif
-template <int R> struct MinWaves { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
+template <int R> struct MinWaves { static constexpr int value = MinWavesOf<R>::value; };
 
 // S = KSpec<...>: the compile-time facts of this instance (generic: only the activation may be fixed; lean: the whole shape).
 // Profiling build only (-DHIPETS_STEP_TRACE, profiles/handover_trace.py): wall-clock stamps (100 MHz, chip-wide) of every
@@ -990,6 +1295,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 #define HIPETS_CROSS_LAYER_PREFETCH 0
 #endif
     constexpr bool kPre = HIPETS_CROSS_LAYER_PREFETCH && kLean && PreOk<S::HIDC>::value && PreOk<S::OUTC>::value;
+    constexpr bool kFuse = S::FUSE && !kPre;  // the output layer's accumulators feed the step's tail directly (KSpec::FUSE)
     // facts that are template arguments in a lean instance and model / call fields in the generic one
     const int normalizer = S::NORM >= 0 ? S::NORM : md.normalizer;
     const int obs_process = S::OBSP >= 0 ? S::OBSP : md.obs_process;
@@ -1020,6 +1326,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
         sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
+        sm.dump = reinterpret_cast<float*>(p); p += 16;
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
@@ -1193,7 +1500,10 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     const int nblk = (md.out_dim + 3) / 4;
     const int Kp0 = md.Kp0;
     Prof prof;
-    prof.on = !kLean && ra.phase_cycles != nullptr && wg == 0 && lane == 0;
+#ifndef HIPETS_LEAN_PROF
+#define HIPETS_LEAN_PROF 0  // profiling builds: the phase profiler also in the shape-specialised instances (profiles/kernel_variants.py)
+#endif
+    prof.on = (!kLean || HIPETS_LEAN_PROF) && ra.phase_cycles != nullptr && wg == 0 && lane == 0;
     prof.slot = sm.prof + wave * 16;
     if (prof.on) {
 #pragma unroll
@@ -1248,7 +1558,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     int kq = Kp0 >> 2;  // column quads per row (the padded input width is a multiple of 16; bf16x3: of 32, set once the layer table is in LDS)
     // The (wave-uniform) normaliser / obs-preprocess switches are resolved ONCE per call into a compile-time variant:
     // with the switches inside, each of the four elements became its own chain of scalar branches and waits.
-    auto build_input_impl = [&](const int t, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
+    auto build_input_impl = [&](const int t, float* const dst, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
         constexpr int NORM = decltype(norm_tag)::value;
         constexpr bool PLAIN = decltype(plain_tag)::value;
         const float* actn_t = sm.actn + (t & 1) * n_act;
@@ -1278,32 +1588,48 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             if constexpr (kB3) {  // three bf16 pieces per value, in the B-operand layout of wave_gemm_b3
                 u32x2 pc[3];
                 split3x4(f32x4{v[0], v[1], v[2], v[3]}, pc);
-                char* row = reinterpret_cast<char*>(sm.buf0) + (size_t)s * md.ld * 4;
+                char* row = reinterpret_cast<char*>(dst) + (size_t)s * md.ld * 4;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(row + b3_offset(4 * cq, p)) = pc[p];
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sm.buf0[s * md.ld + lds_col(4 * cq + q)] = v[q];
+                for (int q = 0; q < 4; ++q) dst[s * md.ld + lds_col(4 * cq + q)] = v[q];
             }
         }
     };
-    auto build_input = [&](const int t) __attribute__((always_inline)) {
+    auto build_input = [&](const int t, float* const dst) __attribute__((always_inline)) {
         using T = std::true_type;
         using F = std::false_type;
         const bool plain = obs_process == HIPETS_OBS_NONE;
         switch (normalizer) {
             case HIPETS_NORM_F64:
-                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, T{});
-                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F64>{}, F{});
+                if (plain) build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_F64>{}, T{});
+                else build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_F64>{}, F{});
                 break;
             case HIPETS_NORM_F32:
-                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F32>{}, T{});
-                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_F32>{}, F{});
+                if (plain) build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_F32>{}, T{});
+                else build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_F32>{}, F{});
                 break;
             default:
-                if (plain) build_input_impl(t, std::integral_constant<int, HIPETS_NORM_NONE>{}, T{});
-                else build_input_impl(t, std::integral_constant<int, HIPETS_NORM_NONE>{}, F{});
+                if (plain) build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_NONE>{}, T{});
+                else build_input_impl(t, dst, std::integral_constant<int, HIPETS_NORM_NONE>{}, F{});
                 break;
+        }
+    };
+    // KSpec::FUSE, FAST form: the obs columns of the next step's input are written by the output layer's tail; the remaining
+    // columns of the padded input -- the normalised actions of step t and the zero padding up to Kp0 -- come from here, element
+    // by element (column obs_in - 1 and column obs_in may share a quad).  Same arithmetic as build_input_impl.
+    auto build_action_columns = [&](const int t, float* const dst) __attribute__((always_inline)) {
+        const float* actn_t = sm.actn + (t & 1) * n_act;
+        const int ntc = Kp0 - md.obs_in;
+        for (int i = tid; i < ROWS * ntc; i += kThreads) {
+            const int s = i / ntc, c = md.obs_in + (i - s * ntc);
+            float v = 0.f;
+            if (c < md.in_dim && sm.rowid[s] >= 0) {
+                const float x = actn_t[s * md.act_dim + (c - md.obs_in)];
+                v = (float)(((double)x - sm.nmean[c]) * sm.nstd[c]);  // KSpec::FUSE instances: f64 normaliser (static_assert in KSpec)
+            }
+            dst[s * md.ld + lds_col(c)] = v;
         }
     };
 
@@ -1324,9 +1650,10 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         cur_op = describe_layer<R, S>(md, sm.lmeta, 0, m0, wave);
         prefetch_issue(cur_op, lane, pre);
     }
-    build_input(ra.t_begin);
+    build_input(ra.t_begin, sm.buf0);
     __syncthreads();
     prof.mark(0);
+    float* step_in = sm.buf0;  // LDS image of the current step's model input (KSpec::FUSE: alternates, see the output layer below)
 
     // Persistent DEVICE form with more logical workgroups than launched ones: within every step this workgroup serves its
     // logical workgroups in turn (sequence index q = step * n_serve + turn); each turn collects its rows from the hand-over
@@ -1342,203 +1669,340 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         const int v_next = wg + ((q_seq + 1) - ((q_seq + 1) / n_serve) * n_serve) * (int)gridDim.x;  // its logical workgroup
         float av[kPrefetch];
         if (more && !persist) fetch_actions_issue(t + 1, av);  // consumed after the sampling phase: the HBM / L2 latency hides behind the MLP
-        const int n_run = expectation ? md.M : 1;
-        float* result = nullptr;
-        int member = 0;
-        for (int mi = 0; mi < n_run; ++mi) {
-            if (expectation) member = mi;
-            else if (fast) member = __builtin_amdgcn_readfirstlane(sm.sched[t]);  // wave-uniform: weight pointers stay in SGPRs
-            else member = domain;
-            if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
-                build_input(t);
-                __syncthreads();
-            }
-            // ---- the MLP: ping-pong through LDS ------------------------------------------------
-            float* cur = sm.buf0;
-            float* nxt = sm.buf1;
-            for (int l = 0; l < md.n_layers; ++l) {
+        unsigned long long* const handover = (more && persist) ? ra.exchange : nullptr;
+        const unsigned long long handover_tag = (unsigned long long)(ra.tag_base + (unsigned)t + 1u) << 32;  // tags never repeat across launches
+        if constexpr (kFuse) {
+            // ---- KSpec::FUSE: hidden layers as usual; the OUTPUT layer's accumulators go straight into the step's tail ----------
+            const int member = fast ? __builtin_amdgcn_readfirstlane(sm.sched[t]) : domain;  // wave-uniform
+            float* cur = step_in;
+            float* nxt = step_in == sm.buf0 ? sm.buf1 : sm.buf0;
+            const int L = md.n_layers;
+            const bool write_input = more && !persist;  // FAST form: rows stay here, the next step's input is built in place
+            for (int l = 0; l + 1 < L; ++l) {
+                // the raw actions of step t + 1 (requested at the top of the step) go to their LDS buffer now: visible to every
+                // thread after this layer's barrier, i.e. when the output layer starts
                 prof.mark(12);
-                if constexpr (kPre) {
-                    NextOp nop;
-                    nop.valid = false;
-                    if (l + 1 < md.n_layers) nop = describe_layer<R, S>(md, sm.lmeta, l + 1, member, wave);
-                    else if (t + 1 < ra.t_end)  // the next step's first op (its member: the schedule's next entry / the same domain)
-                        nop = describe_layer<R, S>(md, sm.lmeta, 0, fast ? __builtin_amdgcn_readfirstlane(sm.sched[t + 1]) : domain, wave);
-                    mlp_layer_pre<R, S>(md, l + 1 == md.n_layers, cur_op, cur, nxt, wave, lane, prof, pre, nop);
-                    cur_op = nop;
-                    lds_barrier();
-                } else if constexpr (kB3) {
-                    mlp_layer_b3<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane);
-                    __syncthreads();
-                } else {
-                    mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
-                    __syncthreads();
-                }
+                if (l == L - 2 && write_input) fetch_actions_commit(t + 1, av);
+                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
             }
-            result = cur;
-
-            if (expectation) {  // gaussian_mlp.py:213-215: mean over members of mean AND (clamped) logvar
-                for (int i = tid; i < ROWS * md.out_total; i += kThreads) {
-                    const int s = i / md.out_total, c = i % md.out_total;
-                    float v = result[s * md.ld + c];
-                    if (!deterministic && c >= md.out_dim) {
-                        const int d = c - md.out_dim;
-                        const int bd = (lv_rows > 1 ? member * md.out_dim : 0) + d;
-                        v = sm.maxlv[bd] - softplus_fast(sm.maxlv[bd] - v);
-                        v = sm.minlv[bd] + softplus_fast(v - sm.minlv[bd]);
+            // `nxt` (the output layer's would-be LDS image) is read by nobody while the output layer runs: it receives the next
+            // step's model input -- action columns and zero padding from all threads here, the obs columns from the tail lanes
+            if (write_input) build_action_columns(t + 1, nxt);
+            const float* const actn_t = sm.actn + (t & 1) * n_act;
+            const unsigned handover_tg = (unsigned)(handover_tag >> 32);
+            // One finished accumulator = column tile c, row tile r of the head-pair pack: this lane (group g, row j) holds
+            // {mean d0, mean d0 + 1, logvar d0, logvar d0 + 1} of batch row s = 16 r + j for d0 = 8 c + 2 g.  Same arithmetic, op for
+            // op, as the LDS-based phases of the other instances (sample_impl / reward phase / build_input_impl below): the
+            // shape-specialised and the generic kernels return the same bits.  BRANCH-FREE on purpose: every lane computes, loads
+            // use clamped indices, stores of inactive lanes go to a dump slot -- so the two or three tails of a wave are one
+            // basic block and the scheduler overlaps their LDS round trips instead of paying them one after the other.
+            auto tail_prep = [&](FusedSlot& q, const int c, const int r) __attribute__((always_inline)) {
+                const int s = r * kTile + (lane & 15);
+                const int d0 = 8 * c + 2 * (lane >> 4);
+                const int dA = min(d0, md.out_dim - 1), dB = min(d0 + 1, md.out_dim - 1);  // clamped: loads stay in bounds
+                const int oA = min(d0, md.obs_dim - 1), oB = min(d0 + 1, md.obs_dim - 1);
+                q.rid = sm.rowid[s];
+                q.mxA = sm.maxlv[dA]; q.mxB = sm.maxlv[dB]; q.mnA = sm.minlv[dA]; q.mnB = sm.minlv[dB];
+                q.pA = sm.state[s * md.obs_dim + oA]; q.pB = sm.state[s * md.obs_dim + oB];
+                q.ndA = sm.nodelta[oA]; q.ndB = sm.nodelta[oB];
+                q.nmA = sm.nmean[oA]; q.nmB = sm.nmean[oB]; q.nsA = sm.nstd[oA]; q.nsB = sm.nstd[oB];
+            };
+            auto tail_unit = [&](const FusedSlot& q, const f32x4 a, const int c, const int r) __attribute__((always_inline)) {
+                const int g = lane >> 4, j = lane & 15;
+                const int s = r * kTile + j;
+                const int d0 = 8 * c + 2 * g;
+                const int rid = q.rid;
+                const bool okA = rid >= 0 && d0 < md.obs_dim, okB = rid >= 0 && d0 + 1 < md.obs_dim;
+                const float mxA = q.mxA, mxB = q.mxB, mnA = q.mnA, mnB = q.mnB, pA = q.pA, pB = q.pB;
+                const bool addA = md.target_is_delta && !q.ndA, addB = md.target_is_delta && !q.ndB;
+                const double nmA = q.nmA, nmB = q.nmB, nsA = q.nsA, nsB = q.nsB;
+                // the two normals of (row, step, dims d0, d0 + 1): half of Philox block d0 / 4, exactly rollout_normals4's
+                float n0, n1;
+                {
+                    const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)(d0 >> 2), (uint32_t)ra.stream_id, (uint32_t)ra.seed,
+                                                     (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32));
+                    const bool upper = (d0 & 2) != 0;
+                    box_muller(upper ? r4.z : r4.x, upper ? r4.w : r4.y, n0, n1);
+                }
+                float lvA = a[2], lvB = a[3];
+                lvA = mxA - softplus_fast(mxA - lvA);  // gaussian_mlp.py:152
+                lvB = mxB - softplus_fast(mxB - lvB);
+                lvA = mnA + softplus_fast(lvA - mnA);  // :153
+                lvB = mnB + softplus_fast(lvB - mnB);
+                const float predA = a[0] + __builtin_amdgcn_sqrtf(exp_hw(lvA)) * n0;  // model.py:471-473
+                const float predB = a[1] + __builtin_amdgcn_sqrtf(exp_hw(lvB)) * n1;
+                const float vA = predA + (addA ? pA : 0.f);  // one_dim_tr_model.py:281-286 (0 for no_delta dims)
+                const float vB = predB + (addB ? pB : 0.f);
+                sm.state[okA ? s * md.obs_dim + d0 : (int)(sm.dump - sm.state)] = vA;
+                sm.state[okB ? s * md.obs_dim + d0 + 1 : (int)(sm.dump - sm.state) + 1] = vB;
+                if (write_input) {  // wave-uniform; build_input_impl's f64 form, OBSP none: input column d = obs dim d
+                    nxt[okA ? s * md.ld + lds_col(d0) : (int)(sm.dump - nxt) + 2] = (float)(((double)vA - nmA) * nsA);
+                    nxt[okB ? s * md.ld + lds_col(d0 + 1) : (int)(sm.dump - nxt) + 3] = (float)(((double)vB - nmB) * nsB);
+                }
+                const unsigned pubA = okA ? __float_as_uint(vA) : 0u, pubB = okB ? __float_as_uint(vB) : 0u;
+                // persistent DEVICE form: the row's next owner waits for these values.  Under a real (divergent) predicate: redirecting
+                // the inactive lanes' stores to one spare row instead made every workgroup's write-through stores queue on ONE
+                // address (measured: 1.375 vs 1.081 ms per cfg2 rollout)
+                if (handover && okA) pair_store(handover + (size_t)rid * NV + d0, pubA, pubB, handover_tg);
+                if (c == 0) {  // wave-uniform.  Reward, termination, masked accumulation (model_env.py:124-129, :186-188) by the lane that holds
+                               // dims 0, 1 of the row; dims 2, 3 sit in the next lane group of the same accumulator.  (A wave can hold
+                               // several c == 0 units -- one per row tile when the output layer has >= 4 column tiles -- hence here, per unit.)
+                    float st[4];
+                    st[0] = okA ? vA : 0.f;
+                    st[1] = okB ? vB : 0.f;
+                    st[2] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubA));
+                    st[3] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubB));
+                    if (g == 0 && rid >= 0) {
+                        float tot = sm.tot[s];
+                        int trm = sm.term[s];
+                        if (persist && sm.pend[s]) {  // collected late: the previous owner published them after ITS output layer (normally long arrived)
+                            sm.pend[s] = 0;
+                            const unsigned long long* const src = ra.exchange + (size_t)rid * NV + (NV - 2);
+                            const unsigned want = ra.tag_base + (unsigned)t;
+                            const long long t_poll = wall_clock64();
+                            u32x4g gq = {0u, 0u, 0u, 0u};
+                            for (int spins = 0;; ++spins) {
+                                pair_load_issue(gq, src);
+                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(gq)::"memory");
+                                if (gq[1] == want && gq[3] == want) break;
+                                if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
+                                    *ra.error_flag = 1;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                            tot = __uint_as_float(gq[0]);
+                            trm = (int)gq[2];
+                        }
+                        float rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
+                        const bool done = term_eval(st, 4, S::TERM);
+                        if (trm) rwd = 0.f;
+                        trm = trm | (done ? 1 : 0);
+                        tot += rwd;
+                        sm.term[s] = trm;
+                        sm.tot[s] = tot;
+                        if (handover) pair_store(handover + (size_t)rid * NV + (NV - 2), __float_as_uint(tot), (unsigned)trm, handover_tg);
+                        else if (persist) ra.totals[rid] = tot;  // last step: the row's return
                     }
-                    sm.expacc[i] = mi == 0 ? v : sm.expacc[i] + v;
+                }
+            };
+            auto tail_finish = [&]() __attribute__((always_inline)) {};
+            const auto tail = make_tail(tail_prep, tail_unit, tail_finish);
+            prof.mark(12);
+            mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail);
+            __syncthreads();
+            prof.mark(8);
+            HIPETS_STAMP(0, t);  // the MLP and the step's tail are done
+            step_in = nxt;
+            if (persist && has_next) {  // the slot's row in the next turn (the tail above was the last reader of this turn's rowid)
+                for (int s = tid; s < ROWS; s += kThreads) {
+                    const int j = (v_next % ra.groups) * ROWS + s;
+                    sm.rowid[s] = j < ra.rows_per_domain
+                                      ? (int)perm_apply((unsigned)((v_next / ra.groups) * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
+                    sm.lrew[s] = 0.f;
                 }
                 __syncthreads();
             }
-        }
+        } else {
+            const int n_run = expectation ? md.M : 1;
+            float* result = nullptr;
+            int member = 0;
+            for (int mi = 0; mi < n_run; ++mi) {
+                if (expectation) member = mi;
+                else if (fast) member = __builtin_amdgcn_readfirstlane(sm.sched[t]);  // wave-uniform: weight pointers stay in SGPRs
+                else member = domain;
+                if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
+                    build_input(t, sm.buf0);
+                    __syncthreads();
+                }
+                // ---- the MLP: ping-pong through LDS ------------------------------------------------
+                float* cur = sm.buf0;
+                float* nxt = sm.buf1;
+                for (int l = 0; l < md.n_layers; ++l) {
+                    prof.mark(12);
+                    if constexpr (kPre) {
+                        NextOp nop;
+                        nop.valid = false;
+                        if (l + 1 < md.n_layers) nop = describe_layer<R, S>(md, sm.lmeta, l + 1, member, wave);
+                        else if (t + 1 < ra.t_end)  // the next step's first op (its member: the schedule's next entry / the same domain)
+                            nop = describe_layer<R, S>(md, sm.lmeta, 0, fast ? __builtin_amdgcn_readfirstlane(sm.sched[t + 1]) : domain, wave);
+                        mlp_layer_pre<R, S>(md, l + 1 == md.n_layers, cur_op, cur, nxt, wave, lane, prof, pre, nop);
+                        cur_op = nop;
+                        lds_barrier();
+                    } else if constexpr (kB3) {
+                        mlp_layer_b3<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane);
+                        __syncthreads();
+                    } else {
+                        mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                        __syncthreads();
+                    }
+                    prof.mark(8);
+                    float* tmp = cur; cur = nxt; nxt = tmp;
+                }
+                result = cur;
 
-        // ---- sample, delta, next obs (model.py:458-473, one_dim_tr_model.py:280-288) -----------
-        // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
-        // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
-        // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
-        HIPETS_STAMP(0, t);  // the MLP is done
-        unsigned long long* const handover = (more && persist) ? ra.exchange : nullptr;
-        const unsigned long long handover_tag = (unsigned long long)(ra.tag_base + (unsigned)t + 1u) << 32;  // tags never repeat across launches
-        auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
-            constexpr bool EXPECT = decltype(expect_tag)::value;
-            constexpr int MODE = decltype(mode_tag)::value;
-            const float inv_m = 1.0f / (float)md.M;
-            const float* lvmin = sm.minlv + (lv_rows > 1 ? member * md.out_dim : 0);  // this step's member owns the bounds
-            const float* lvmax = sm.maxlv + (lv_rows > 1 ? member * md.out_dim : 0);
-            for (int item = tid; item < ROWS * nblk; item += kThreads) {
-                const int s = item / nblk, blk = item % nblk;
-                const int rid = sm.rowid[s];
-                if (rid < 0) continue;
-                float nrm[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (MODE == 1) {
-#pragma unroll
+                if (expectation) {  // gaussian_mlp.py:213-215: mean over members of mean AND (clamped) logvar
+                    for (int i = tid; i < ROWS * md.out_total; i += kThreads) {
+                        const int s = i / md.out_total, c = i % md.out_total;
+                        float v = result[s * md.ld + c];
+                        if (!deterministic && c >= md.out_dim) {
+                            const int d = c - md.out_dim;
+                            const int bd = (lv_rows > 1 ? member * md.out_dim : 0) + d;
+                            v = sm.maxlv[bd] - softplus_fast(sm.maxlv[bd] - v);
+                            v = sm.minlv[bd] + softplus_fast(v - sm.minlv[bd]);
+                        }
+                        sm.expacc[i] = mi == 0 ? v : sm.expacc[i] + v;
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // ---- sample, delta, next obs (model.py:458-473, one_dim_tr_model.py:280-288) -----------
+            // MODE 0: prediction = mean (deterministic model, or no eps given); 1: injected eps; 2: in-kernel Philox.
+            // Wave-uniform switches are hoisted into compile-time variants so the four per-dimension chains
+            // (LDS read -> 2 softplus -> exp -> sqrt -> fma) are straight-line code and interleave.
+            HIPETS_STAMP(0, t);  // the MLP is done
+            auto sample_impl = [&](auto expect_tag, auto mode_tag) __attribute__((always_inline)) {
+                constexpr bool EXPECT = decltype(expect_tag)::value;
+                constexpr int MODE = decltype(mode_tag)::value;
+                const float inv_m = 1.0f / (float)md.M;
+                const float* lvmin = sm.minlv + (lv_rows > 1 ? member * md.out_dim : 0);  // this step's member owns the bounds
+                const float* lvmax = sm.maxlv + (lv_rows > 1 ? member * md.out_dim : 0);
+                for (int item = tid; item < ROWS * nblk; item += kThreads) {
+                    const int s = item / nblk, blk = item % nblk;
+                    const int rid = sm.rowid[s];
+                    if (rid < 0) continue;
+                    float nrm[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MODE == 1) {
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int d = min(blk * 4 + q, md.out_dim - 1);
+                            nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
+                        }
+                    } else if constexpr (MODE == 2) {
+                        rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
+                    }
+                    float pred[4], prev[4];
+    #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int d = min(blk * 4 + q, md.out_dim - 1);
-                        nrm[q] = ra.eps[((size_t)t * ra.B + rid) * md.out_dim + d];
+                        float mean, lv = 0.f;
+                        if constexpr (EXPECT) {
+                            mean = sm.expacc[s * md.out_total + d] / (float)md.M;
+                            if constexpr (MODE != 0) lv = sm.expacc[s * md.out_total + md.out_dim + d] / (float)md.M;
+                        } else {
+                            mean = result[s * md.ld + d];
+                            if constexpr (MODE != 0) {
+                                lv = result[s * md.ld + md.out_dim + d];
+                                lv = lvmax[d] - softplus_fast(lvmax[d] - lv);  // gaussian_mlp.py:152
+                                lv = lvmin[d] + softplus_fast(lv - lvmin[d]);  // :153
+                            }
+                        }
+                        if constexpr (MODE != 0) pred[q] = mean + __builtin_amdgcn_sqrtf(exp_hw(lv)) * nrm[q];  // model.py:471-473
+                        else pred[q] = mean;
+                        const int do_ = min(d, md.obs_dim - 1);
+                        prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
                     }
-                } else if constexpr (MODE == 2) {
-                    rollout_normals4(rid, t, blk, ra.seed, ra.stream_id, nrm);
-                }
-                float pred[4], prev[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int d = min(blk * 4 + q, md.out_dim - 1);
-                    float mean, lv = 0.f;
-                    if constexpr (EXPECT) {
-                        mean = sm.expacc[s * md.out_total + d] / (float)md.M;
-                        if constexpr (MODE != 0) lv = sm.expacc[s * md.out_total + md.out_dim + d] / (float)md.M;
-                    } else {
-                        mean = result[s * md.ld + d];
-                        if constexpr (MODE != 0) {
-                            lv = result[s * md.ld + md.out_dim + d];
-                            lv = lvmax[d] - softplus_fast(lvmax[d] - lv);  // gaussian_mlp.py:152
-                            lv = lvmin[d] + softplus_fast(lv - lvmin[d]);  // :153
+                    (void)inv_m;
+                    unsigned pub[4] = {0u, 0u, 0u, 0u};
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int d = blk * 4 + q;
+                        if (d < md.obs_dim) {
+                            const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
+                            sm.state[s * md.obs_dim + d] = nobs;
+                            pub[q] = __float_as_uint(nobs);
+                            if (trace_next_obs) trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
+                        } else if (d < md.out_dim) {
+                            sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
                         }
                     }
-                    if constexpr (MODE != 0) pred[q] = mean + __builtin_amdgcn_sqrtf(exp_hw(lv)) * nrm[q];  // model.py:471-473
-                    else pred[q] = mean;
-                    const int do_ = min(d, md.obs_dim - 1);
-                    prev[q] = (md.target_is_delta && !sm.nodelta[do_]) ? sm.state[s * md.obs_dim + do_] : 0.f;
-                }
-                (void)inv_m;
-                unsigned pub[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int d = blk * 4 + q;
-                    if (d < md.obs_dim) {
-                        const float nobs = pred[q] + prev[q];  // one_dim_tr_model.py:281-286 (prev = 0 for no_delta dims)
-                        sm.state[s * md.obs_dim + d] = nobs;
-                        pub[q] = __float_as_uint(nobs);
-                        if (trace_next_obs) trace_next_obs[((size_t)t * ra.B + rid) * md.obs_dim + d] = nobs;
-                    } else if (d < md.out_dim) {
-                        sm.lrew[s] = pred[q];  // learned reward = last output (one_dim_tr_model.py:287)
+                    // persistent DEVICE form: the row's next owner waits for these values -- on their way before the reward phase
+                    if (handover) {
+                        const unsigned tg = (unsigned)(handover_tag >> 32);
+                        if (blk * 4 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4, pub[0], pub[1], tg);
+                        if (blk * 4 + 2 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4 + 2, pub[2], pub[3], tg);
                     }
                 }
-                // persistent DEVICE form: the row's next owner waits for these values -- on their way before the reward phase
-                if (handover) {
-                    const unsigned tg = (unsigned)(handover_tag >> 32);
-                    if (blk * 4 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4, pub[0], pub[1], tg);
-                    if (blk * 4 + 2 < md.obs_dim) pair_store(handover + (size_t)rid * NV + blk * 4 + 2, pub[2], pub[3], tg);
+            };
+            {
+                using T = std::true_type;
+                using F = std::false_type;
+                // lean instances: stochastic model, in-kernel Philox draws (the host selects them only then)
+                const int mode = kLean ? 2 : (deterministic ? 0 : (ra.eps != nullptr ? 1 : (ra.use_philox ? 2 : 0)));
+                if (expectation) {
+                    if (mode == 0) sample_impl(T{}, std::integral_constant<int, 0>{});
+                    else if (mode == 1) sample_impl(T{}, std::integral_constant<int, 1>{});
+                    else sample_impl(T{}, std::integral_constant<int, 2>{});
+                } else {
+                    if (mode == 0) sample_impl(F{}, std::integral_constant<int, 0>{});
+                    else if (mode == 1) sample_impl(F{}, std::integral_constant<int, 1>{});
+                    else sample_impl(F{}, std::integral_constant<int, 2>{});
                 }
             }
-        };
-        {
-            using T = std::true_type;
-            using F = std::false_type;
-            // lean instances: stochastic model, in-kernel Philox draws (the host selects them only then)
-            const int mode = kLean ? 2 : (deterministic ? 0 : (ra.eps != nullptr ? 1 : (ra.use_philox ? 2 : 0)));
-            if (expectation) {
-                if (mode == 0) sample_impl(T{}, std::integral_constant<int, 0>{});
-                else if (mode == 1) sample_impl(T{}, std::integral_constant<int, 1>{});
-                else sample_impl(T{}, std::integral_constant<int, 2>{});
-            } else {
-                if (mode == 0) sample_impl(F{}, std::integral_constant<int, 0>{});
-                else if (mode == 1) sample_impl(F{}, std::integral_constant<int, 1>{});
-                else sample_impl(F{}, std::integral_constant<int, 2>{});
-            }
-        }
-        if (more && !persist) fetch_actions_commit(t + 1, av);
-        __syncthreads();
-        prof.mark(9);
+            if (more && !persist) fetch_actions_commit(t + 1, av);
+            __syncthreads();
+            prof.mark(9);
 
-        // ---- reward, termination, masked accumulation (model_env.py:124-129, :186-188) of step t, and, in the
-        // same barrier interval, the model input of step t+1 (both only READ the new state) ------------------
-        // Persistent DEVICE form: every row changes workgroups now.  Its new state left in the sampling phase; its running
-        // total and flag follow from here, and the same thread then evaluates which row the slot holds in step t + 1.
-        for (int s = tid; s < ROWS; s += kThreads) {
-            const int rid = sm.rowid[s];
-            if (rid >= 0) {
-                const float* st = sm.state + s * md.obs_dim;
-                const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
-                float tot = sm.tot[s];
-                int trm = sm.term[s];
-                if (persist && sm.pend[s]) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
-                    sm.pend[s] = 0;
-                    const unsigned long long* const src = ra.exchange + (size_t)rid * NV + (NV - 2);
-                    const unsigned want = ra.tag_base + (unsigned)t;
-                    const long long t_poll = wall_clock64();
-                    u32x4g g = {0u, 0u, 0u, 0u};
-                    for (int spins = 0;; ++spins) {
-                        pair_load_issue(g, src);
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
-                        if (g[1] == want && g[3] == want) break;
-                        if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
-                            *ra.error_flag = 1;
-                            break;
+            // ---- reward, termination, masked accumulation (model_env.py:124-129, :186-188) of step t, and, in the
+            // same barrier interval, the model input of step t+1 (both only READ the new state) ------------------
+            // Persistent DEVICE form: every row changes workgroups now.  Its new state left in the sampling phase; its running
+            // total and flag follow from here, and the same thread then evaluates which row the slot holds in step t + 1.
+            for (int s = tid; s < ROWS; s += kThreads) {
+                const int rid = sm.rowid[s];
+                if (rid >= 0) {
+                    const float* st = sm.state + s * md.obs_dim;
+                    const float* ac = sm.actn + (t & 1) * ROWS * md.act_dim + s * md.act_dim;
+                    float tot = sm.tot[s];
+                    int trm = sm.term[s];
+                    if (persist && sm.pend[s]) {  // collected late: the previous owner published them after ITS reward phase (normally long arrived)
+                        sm.pend[s] = 0;
+                        const unsigned long long* const src = ra.exchange + (size_t)rid * NV + (NV - 2);
+                        const unsigned want = ra.tag_base + (unsigned)t;
+                        const long long t_poll = wall_clock64();
+                        u32x4g g = {0u, 0u, 0u, 0u};
+                        for (int spins = 0;; ++spins) {
+                            pair_load_issue(g, src);
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
+                            if (g[1] == want && g[3] == want) break;
+                            if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
+                                *ra.error_flag = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
                         }
-                        __builtin_amdgcn_s_sleep(8);
+                        tot = __uint_as_float(g[0]);
+                        trm = (int)g[2];
                     }
-                    tot = __uint_as_float(g[0]);
-                    trm = (int)g[2];
+                    float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
+                    const bool done = term_eval(st, md.obs_dim, term_fn);
+                    if (trace_rewards) trace_rewards[(size_t)t * ra.B + rid] = r;
+                    if (trm) r = 0.f;
+                    trm = trm | (done ? 1 : 0);
+                    tot += r;
+                    sm.term[s] = trm;
+                    sm.tot[s] = tot;
+                    if (handover) {
+                        pair_store(handover + (size_t)rid * NV + (NV - 2), __float_as_uint(tot), (unsigned)trm, (unsigned)(handover_tag >> 32));
+                    } else if (persist) {
+                        ra.totals[rid] = tot;  // last step: the row's return
+                    }
                 }
-                float r = reward_eval(st, ac, md.obs_dim, md.act_dim, reward_fn, sm.lrew[s]);
-                const bool done = term_eval(st, md.obs_dim, term_fn);
-                if (trace_rewards) trace_rewards[(size_t)t * ra.B + rid] = r;
-                if (trm) r = 0.f;
-                trm = trm | (done ? 1 : 0);
-                tot += r;
-                sm.term[s] = trm;
-                sm.tot[s] = tot;
-                if (handover) {
-                    pair_store(handover + (size_t)rid * NV + (NV - 2), __float_as_uint(tot), (unsigned)trm, (unsigned)(handover_tag >> 32));
-                } else if (persist) {
-                    ra.totals[rid] = tot;  // last step: the row's return
+                if (persist && has_next) {  // the slot's row in the next turn (only this thread reads rowid[s] between the two barriers around here)
+                    const int j = (v_next % ra.groups) * ROWS + s;
+                    sm.rowid[s] = j < ra.rows_per_domain
+                                      ? (int)perm_apply((unsigned)((v_next / ra.groups) * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
+                    sm.lrew[s] = 0.f;
                 }
             }
-            if (persist && has_next) {  // the slot's row in the next turn (only this thread reads rowid[s] between the two barriers around here)
-                const int j = (v_next % ra.groups) * ROWS + s;
-                sm.rowid[s] = j < ra.rows_per_domain
-                                  ? (int)perm_apply((unsigned)((v_next / ra.groups) * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
-                sm.lrew[s] = 0.f;
-            }
-        }
-        if (more && !persist) build_input(t + 1);
-        __syncthreads();
-        prof.mark(10);
+            if (more && !persist) build_input(t + 1, sm.buf0);
+            __syncthreads();
+            prof.mark(10);
 
+        }
         HIPETS_STAMP(1, t);  // sampled, rewarded, published
         if (persist && has_next) {
             // ---- collect the rows of the next turn: 8-byte {value bits, step tag} granules, self-validating ----
@@ -1622,7 +2086,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             HIPETS_STAMP(2, t);  // this thread's rows have arrived
             fetch_actions_commit(t_next, av2);
             __syncthreads();
-            build_input(t_next);
+            build_input(t_next, step_in);
             __syncthreads();
             HIPETS_STAMP(3, t);  // the next step's input is built
         }

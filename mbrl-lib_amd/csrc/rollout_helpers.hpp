@@ -95,8 +95,10 @@ __global__ void step_keys_kernel(PermKeys* keys, int H, unsigned long long seed,
 //   dst[m][l][c][kk][lane][s] = W_l[members[m]][16*kk + 4*s + (lane>>4)][16*c + colperm(lane&15)]   (0 outside K x N)
 // so that k-step s of a chunk holds 4 CONSECUTIVE k (the tail chunk's all-padding steps can be skipped).
 // src_nk != 0: the source is [E, N, K] row-major (nn.Linear's [out, in]) instead of [E, K, N] (EnsembleLinearLayer).
+// permute_cols: 0 natural columns, 1 hidden layers (lds_col inside every 16), 2 the output layer's "head pair" order
+// (head_pair_col(p, head_dim): means and log-variances of two output dims per lane group; N = 2 head_dim)
 __global__ void pack_weights_kernel(float* dst, const float* src, const int* members, int M, int K, int N, int Kp,
-                                    int Np, long long member_stride, long long layer_off, int permute_cols, int src_nk) {
+                                    int Np, long long member_stride, long long layer_off, int permute_cols, int src_nk, int head_dim = 0) {
     const long long per_member = (long long)Kp * Np;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_member * M) return;
@@ -110,9 +112,10 @@ __global__ void pack_weights_kernel(float* dst, const float* src, const int* mem
     const int k = 16 * kk + 4 * s + (lane >> 4);  // MFMA k-step s of a chunk covers k = 16 kk + 4 s + {0,1,2,3}
     // fragment row (lane & 15) = index m of the transposed product D^T[m][batch row]; hidden layers map it to the
     // real column lds_col(m) so that accumulator register i of lane group g lands on LDS position 4g + i
-    const int n = 16 * c + (permute_cols ? lds_col(lane & 15) : (lane & 15));
+    int n = 16 * c + (permute_cols == 1 ? lds_col(lane & 15) : (lane & 15));
+    if (permute_cols == 2) n = head_pair_col(n, head_dim);
     float v = 0.f;
-    if (k < K && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
+    if (k < K && n >= 0 && n < N) v = src_nk ? src[((size_t)members[m] * N + n) * K + k] : src[((size_t)members[m] * K + k) * N + n];
     dst[(size_t)m * member_stride + layer_off + (i % per_member)] = v;
 }
 
@@ -149,12 +152,13 @@ __global__ void pack_weights_b3_kernel(uint4* dst, const float* src, const int* 
 }
 
 __global__ void pack_bias_kernel(float* dst, const float* src, const int* members, int M, int N, int Np, int member_stride,
-                                 int layer_off, int permute_cols) {
+                                 int layer_off, int permute_cols, int head_dim = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * Np) return;
     const int m = i / Np, np_ = i % Np;
-    const int n = permute_cols ? lds_col(np_) : np_;  // same permutation as the weight columns
-    dst[(size_t)m * member_stride + layer_off + np_] = n < N ? src[(size_t)members[m] * N + n] : 0.f;
+    int n = permute_cols == 1 ? lds_col(np_) : np_;  // same permutation as the weight columns
+    if (permute_cols == 2) n = head_pair_col(np_, head_dim);
+    dst[(size_t)m * member_stride + layer_off + np_] = (n >= 0 && n < N) ? src[(size_t)members[m] * N + n] : 0.f;
 }
 
 }  // namespace hipets

@@ -115,3 +115,37 @@ def test_header_is_plain_c_and_the_c_client_links():
 
     ge.build_c_client(force=True)
     assert os.path.exists(ge.C_CLIENT)
+
+
+def test_no_kernel_of_the_shipped_library_uses_scratch_memory():
+    """The compiler's own resource report of every kernel (recorded by __graft_entry__.build_library next to the library):
+    zero bytes of scratch.  Register-resident fragment arrays are what the rollout kernel's k loop lives on; one dynamically
+    indexed array (a loop the compiler did not unroll) moves them to scratch memory without any diagnostic -- same results,
+    28 ms instead of 1 ms per rollout (round 3, caught by timing only) -- and an instantiation too many pushes a kernel that
+    sits at the 256-VGPR limit into spilling.  Known exceptions, each by design or on record: the coloured-noise sampler keeps
+    its H/2+1 spectrum coefficients in a per-thread array; the R = 2 instances of the separately reported bf16x3 arithmetic
+    mode spill 8-35 VGPRs."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    ge.build_library()
+    info = json.load(open(ge.BUILDINFO))
+    kernels = info.get("kernels", {})
+    rollout = [k for k in kernels if "rollout_kernel" in k]
+    assert len(rollout) >= 20, "the resource report of the rollout-kernel instances is missing from the buildinfo file"
+
+    def allowed(name):
+        if "icem_sample_kernel" in name:
+            return True
+        m = re.search(r"rollout_kernelILi(\d+)ENS_5KSpecI(.*?)EEEEE", name)
+        if not m:
+            return False
+        args = [int(a.replace("Li", "").replace("n", "-").rstrip("E")) for a in re.findall(r"Lin?\d+E", m.group(2))]
+        return int(m.group(1)) == 2 and len(args) >= 9 and args[8] == 1  # R = 2, PREC = bf16x3
+
+    for name, r in kernels.items():
+        if not allowed(name):
+            assert r.get("ScratchSize [bytes/lane]", 0) == 0, (name, r)

@@ -122,13 +122,20 @@ def test_resolver_produces_plain_values():
 @pytest.mark.parametrize("target", ["stock", "hipets"])
 def test_stock_optimizer_configs_build_and_plan_through_the_hydra_seam(name, target):
     import hipets
-    from test_host_logic import _DictConfigLike, _FakeModelEnv
+    from test_host_logic import _DictConfigLike, _FakeMLP, _FakeModelEnv
 
     dev = "cuda:0"
     me = _FakeModelEnv()
     me.device = dev
-    for layer in me.dynamics_model.model.hidden_layers:
-        torch.nn.init.normal_(layer[0].weight, std=0.3)
+    # five members like the elite set the stock overrides train with (num_elites: 5): 20 particles x any population is a
+    # multiple of 5 (gaussian_mlp.py:195-200; SURVEY Appendix B7 -- with all 7 members iCEM's last iteration could not run)
+    E, obs, act, hid = 5, 5, 2, 8
+    g = torch.Generator().manual_seed(0)
+    five = hipets.ModelSpec(weights=[torch.randn(E, obs + act, hid, generator=g) * 0.3, torch.randn(E, hid, hid, generator=g) * 0.3,
+                                     torch.randn(E, hid, 2 * obs, generator=g) * 0.1],
+                            biases=[torch.zeros(E, 1, hid), torch.zeros(E, 1, hid), torch.zeros(E, 1, 2 * obs)], obs_dim=obs, act_dim=act,
+                            min_logvar=-10 * torch.ones(1, obs), max_logvar=0.5 * torch.ones(1, obs))
+    me.dynamics_model.model = _FakeMLP(five, torch.nn.SiLU())
     opt_cfg = resolved(name, dev)
     if target == "hipets":  # the documented opt-in: action_optimizer._target_=hipets.<Class>, algorithm.agent._target_=hipets.TrajectoryOptimizerAgent
         opt_cfg["_target_"] = opt_cfg["_target_"].replace("mbrl.planning", "hipets")
@@ -137,8 +144,6 @@ def test_stock_optimizer_configs_build_and_plan_through_the_hydra_seam(name, tar
     if target == "hipets":
         agent_cfg["_target_"] = "hipets.TrajectoryOptimizerAgent"
     agent_cfg = _DictConfigLike(**agent_cfg)
-    # the fake model has 5 members; the stock iCEM module is the stock ensemble size 7: particles must make rows % members == 0
-    # for every population the optimizer evaluates, which 20 particles on 5 members do
     agent = hipets.create_trajectory_optim_agent_for_model(me, agent_cfg, num_particles=NUM_PARTICLES)
     opt = agent.optimizer.optimizer
     v = OVERRIDES[name][1]
