@@ -1619,8 +1619,34 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     // KSpec::FUSE, FAST form: the obs columns of the next step's input are written by the output layer's tail; the remaining
     // columns of the padded input -- the normalised actions of step t and the zero padding up to Kp0 -- come from here, element
     // by element (column obs_in - 1 and column obs_in may share a quad).  Same arithmetic as build_input_impl.
+    // This thread's column of those (<= 16 action + padding columns, the usual case): column obs_in + (tid & 15), rows tid / 16 + 16 q --
+    // no division, the column's normaliser constants and LDS position fixed for the launch.
+    const int bac_c = md.obs_in + (tid & 15);
+    const bool bac_fast = kFuse && Kp0 - md.obs_in <= 16;
+    const bool bac_live = bac_fast && bac_c < md.in_dim;  // an action column (else zero padding, or beyond Kp0: nothing to write)
+    double bac_nm = 0.0, bac_ns = 0.0;  // read from LDS once the prologue has put the constants there (below)
+    const int bac_pos = lds_col(min(bac_c, Kp0 - 1));
     auto build_action_columns = [&](const int t, float* const dst) __attribute__((always_inline)) {
         const float* actn_t = sm.actn + (t & 1) * n_act;
+        if (bac_fast) {
+            if (bac_c < Kp0) {
+                constexpr int kPasses = (ROWS + 15) / 16;
+                float x[kPasses];
+                int rid[kPasses];
+#pragma unroll
+                for (int q = 0; q < kPasses; ++q) {  // all LDS reads first: one round trip for the thread's rows
+                    const int s = (tid >> 4) + 16 * q;
+                    rid[q] = s < ROWS ? sm.rowid[s] : -1;
+                    x[q] = (bac_live && s < ROWS) ? actn_t[s * md.act_dim + (bac_c - md.obs_in)] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < kPasses; ++q) {
+                    const int s = (tid >> 4) + 16 * q;
+                    if (s < ROWS) dst[s * md.ld + bac_pos] = (bac_live && rid[q] >= 0) ? (float)(((double)x[q] - bac_nm) * bac_ns) : 0.f;
+                }
+            }
+            return;
+        }
         const int ntc = Kp0 - md.obs_in;
         for (int i = tid; i < ROWS * ntc; i += kThreads) {
             const int s = i / ntc, c = md.obs_in + (i - s * ntc);
@@ -1641,6 +1667,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         fetch_actions_commit(ra.t_begin, av);
     }
     __syncthreads();
+    if (bac_live) { bac_nm = sm.nmean[bac_c]; bac_ns = sm.nstd[bac_c]; }
     if constexpr (kB3) kq = sm.lmeta[0].Kp32 >> 2;
     Pre pre;      // chunk-0 weight fragments + biases of the NEXT linear op of this wave (kPre kernels)
     NextOp cur_op;  // ... and that op's descriptor
