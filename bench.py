@@ -423,13 +423,21 @@ def main():
         for _ in range(3):
             ag.act(s0)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        # act() returns host data, so it is synchronous by construction: per-call wall times.  A generation-2 pass of Python's
+        # garbage collector landing inside the loop costs one act ~40 ms (and the idle GPU a few acts of clock ramp after it):
+        # collect before the loop, and report the median beside the mean so that such a host pause is visible, not averaged in
+        import gc
+        gc.collect()
         na = max(5, args.steps // 2)
+        per_act = []
         for _ in range(na):
+            t0 = time.perf_counter()
             ag.act(s0)
-        ea = time.perf_counter() - t0  # act() returns host data: it is synchronous by construction
+            per_act.append(time.perf_counter() - t0)
+        ea = sum(per_act)
         extras["agent_act"] = {"workload": f"hipets.TrajectoryOptimizerAgent.act(obs) on configs[1] (mode='{args.mode}'), host observation in, host action out",
-                               "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea}
+                               "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea, "ms_per_act_median": 1e3 * float(np.median(per_act)),
+                               "ms_per_act_max": 1e3 * max(per_act), "acts": na}
 
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     plans_done = args.steps * (world if sharded == "fallback" else 1)  # fallback: every rank planned on its own

@@ -37,8 +37,18 @@ def rollout_row(stats_csv, names=("rollout_kernel",)):
         return None
     calls = sum(int(r["Calls"]) for r in rows)
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    return {"kernels": [r["Name"][:120] for r in rows], "calls": calls, "avg_ns": total / calls, "min_ns": min(float(r["MinNs"]) for r in rows),
-            "max_ns": max(float(r["MaxNs"]) for r in rows), "pct_of_gpu_time": sum(float(r["Percentage"]) for r in rows)}
+    out = {"kernels": [r["Name"][:120] for r in rows], "calls": calls, "avg_ns": total / calls, "min_ns": min(float(r["MinNs"]) for r in rows),
+           "max_ns": max(float(r["MaxNs"]) for r in rows), "pct_of_gpu_time": sum(float(r["Percentage"]) for r in rows)}
+    # The persistent DEVICE form validates co-residency ONCE per process with a self-test launch of the very same kernel (a few
+    # microseconds: every workgroup arrives at a counter and returns; rollout.hpp RolloutArgs::census).  rocprofv3 files it under
+    # the rollout kernel's name; bench.py's hipEvents do not cover it.  Reported separately, so that the two averages compare.
+    if len(rows) == 1 and out["min_ns"] < 0.05 * out["avg_ns"] and calls > 2:
+        out["self_test_launches_excluded"] = 1
+        out["self_test_ns"] = out["min_ns"]
+        out["avg_ns_including_the_self_test_launch"] = out["avg_ns"]
+        out["avg_ns"] = (total - out["min_ns"]) / (calls - 1)
+        out["calls"] = calls - 1
+    return out
 
 
 out, traffic = {"tag": tag}, {}
@@ -61,6 +71,10 @@ for mode in ("device", "fast"):
             counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
             meta = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
                                          "Accum_VGPR_Count", "SGPR_Count") if k in row}
+    # (the one co-residency self-test launch of DEVICE mode -- same kernel name, ~1e-3 of a rollout's counters -- is not a rollout)
+    for k, v in list(counters.items()):
+        med = sorted(v)[len(v) // 2]
+        counters[k] = [x for x in v if not (med > 0 and x < 0.05 * med)]
     avg = {k: sum(v) / len(v) for k, v in counters.items()}
     roll = rollout_row(stats)
     d = {}
