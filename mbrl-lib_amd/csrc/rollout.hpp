@@ -527,6 +527,25 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         for (int r = 0; r < R; ++r) acc[ct][r] = CT > 0 ? bv[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < EXn; ++e) accx[e] = EX > 0 ? bvx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    // Pin every accumulator's initial value HERE: to the compiler an asm MFMA is an ordinary reader of its C operand, so it may
+    // sink the (VALU) initialisation -- a copy of the bias, the zeros of the odd-k-step accumulators -- down to just in front of
+    // the first MFMA that uses the register, inside a k-step, behind that k-step's s_nop: a VALU write followed at once by an MFMA
+    // reading it as SrcC (hazard (1) below; found in the ISA of the cfg4 instances by tests/test_isa_hazards.py, where it returned
+    // wrong sums).  An empty asm that "modifies" the register makes the value opaque: it must be complete before this point.
+    auto pin = [](f32x4& v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); };
+#pragma unroll
+    for (int ct = 0; ct < CTn; ++ct)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (CT > 0) pin(acc[ct][r]);
+            if constexpr (CT > 0 && kSplitAll) pin(acco[ct][r]);
+        }
+#pragma unroll
+    for (int e = 0; e < EXn; ++e) {
+        if constexpr (EX > 0) pin(accx[e]);
+        if constexpr (EX > 0 && kSplitAll) pin(accxo[e]);
+    }
+    if constexpr (kSplit) pin(acc_odd);
     prof.mark(14);
     if constexpr (KCS > 0) {
         constexpr int kEnd = KCS >= 2 ? ((KCS - 1) / 2) * 2 : 0;  // the loop below leaves kk at the smallest even number >= KCS - 2
@@ -1518,15 +1537,33 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     constexpr int kPrefetch = 4;
     const int n_act = ROWS * md.act_dim;
     long long act_base[kPrefetch];  // element offset of (candidate, t = 0, a); -1 = nothing to fetch
-    auto compute_act_base = [&]() __attribute__((always_inline)) {  // from sm.rowid (again whenever the workgroup's rows change)
+    // (row slot, action dim) of this thread's elements never change; the candidate of a row id (rid / P) by multiply-high with
+    // ceil(2^32 / P): exact while rid * P < 2^32 (B * P: 2e5 x 20 at cfg2), else the division itself
+    int act_s[kPrefetch], act_a[kPrefetch];
+#pragma unroll
+    for (int q = 0; q < kPrefetch; ++q) {
+        const int i = tid + q * kThreads;
+        act_s[q] = i < n_act ? i / md.act_dim : -1;
+        act_a[q] = i < n_act ? i - (i / md.act_dim) * md.act_dim : 0;
+    }
+#ifdef HIPETS_DBG_NOMAGIC
+    const bool magic_ok = false;
+#else
+    const bool magic_ok = ra.P > 1 && (unsigned long long)ra.B * (unsigned)ra.P < 0x100000000ull;  // (P = 1: the constant would be 2^32)
+#endif
+    const unsigned magic_p = (unsigned)(0x100000000ull / (unsigned)max(ra.P, 2)) + 1u;
+    const int act_stride = ra.H * md.act_dim;
+    // whose rows the action fetch / action columns are for: the slot's current rows -- except in the straight persistent form
+    // (below), where the actions of step t + 1 are fetched during step t for the rows the slot will hold THEN
+    const int* act_rows = sm.rowid;
+    auto compute_act_base = [&]() __attribute__((always_inline)) {  // from act_rows (again whenever the workgroup's rows change)
 #pragma unroll
         for (int q = 0; q < kPrefetch; ++q) {
-            const int i = tid + q * kThreads;
             act_base[q] = -1;
-            if (i < n_act) {
-                const int s = i / md.act_dim, a = i % md.act_dim;
-                const int rid = sm.rowid[s];
-                if (rid >= 0) act_base[q] = (long long)(rid / ra.P) * ra.H * md.act_dim + a;
+            if (act_s[q] >= 0) {
+                const int rid = act_rows[act_s[q]];
+                const int cand = magic_ok ? (int)__umulhi((unsigned)rid, magic_p) : rid / ra.P;
+                if (rid >= 0) act_base[q] = (long long)cand * act_stride + act_a[q];
             }
         }
     };
@@ -1535,7 +1572,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         float* actn_t = sm.actn + (t & 1) * n_act;
         for (int i = tid + kPrefetch * kThreads; i < n_act; i += kThreads) {
             const int s = i / md.act_dim, a = i % md.act_dim;
-            const int rid = sm.rowid[s];
+            const int rid = act_rows[s];
             actn_t[i] = rid >= 0 ? ra.actions[((size_t)(rid / ra.P) * ra.H + t) * md.act_dim + a] : 0.f;
         }
     };
@@ -1626,22 +1663,26 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     const bool bac_live = bac_fast && bac_c < md.in_dim;  // an action column (else zero padding, or beyond Kp0: nothing to write)
     double bac_nm = 0.0, bac_ns = 0.0;  // read from LDS once the prologue has put the constants there (below)
     const int bac_pos = lds_col(min(bac_c, Kp0 - 1));
+    // (fast path: by the waves 1 .. kWaves - 1 only -- the output layer deals its leftover units to wave 0 first, so the others
+    // reach the layer's barrier early by at least one unit's k loop and this work disappears in that slack; 12 rows per pass)
     auto build_action_columns = [&](const int t, float* const dst) __attribute__((always_inline)) {
         const float* actn_t = sm.actn + (t & 1) * n_act;
         if (bac_fast) {
-            if (bac_c < Kp0) {
-                constexpr int kPasses = (ROWS + 15) / 16;
+            if (wave != 0 && bac_c < Kp0) {
+                constexpr int kRowsPerPass = (kThreads - 64) / 16;
+                constexpr int kPasses = (ROWS + kRowsPerPass - 1) / kRowsPerPass;
+                const int r0 = (tid - 64) >> 4;
                 float x[kPasses];
                 int rid[kPasses];
 #pragma unroll
                 for (int q = 0; q < kPasses; ++q) {  // all LDS reads first: one round trip for the thread's rows
-                    const int s = (tid >> 4) + 16 * q;
-                    rid[q] = s < ROWS ? sm.rowid[s] : -1;
+                    const int s = r0 + kRowsPerPass * q;
+                    rid[q] = s < ROWS ? act_rows[s] : -1;
                     x[q] = (bac_live && s < ROWS) ? actn_t[s * md.act_dim + (bac_c - md.obs_in)] : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < kPasses; ++q) {
-                    const int s = (tid >> 4) + 16 * q;
+                    const int s = r0 + kRowsPerPass * q;
                     if (s < ROWS) dst[s * md.ld + bac_pos] = (bac_live && rid[q] >= 0) ? (float)(((double)x[q] - bac_nm) * bac_ns) : 0.f;
                 }
             }
@@ -1651,7 +1692,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         for (int i = tid; i < ROWS * ntc; i += kThreads) {
             const int s = i / ntc, c = md.obs_in + (i - s * ntc);
             float v = 0.f;
-            if (c < md.in_dim && sm.rowid[s] >= 0) {
+            if (c < md.in_dim && act_rows[s] >= 0) {
                 const float x = actn_t[s * md.act_dim + (c - md.obs_in)];
                 v = (float)(((double)x - sm.nmean[c]) * sm.nstd[c]);  // KSpec::FUSE instances: f64 normaliser (static_assert in KSpec)
             }
@@ -1688,6 +1729,88 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     // turns of the previous step); the later turns' rows arrived while the earlier ones computed.
     const int n_serve = persist ? (ra.n_logical - wg + (int)gridDim.x - 1) / (int)gridDim.x : 1;
     const int n_seq = (ra.t_end - ra.t_begin) * n_serve;
+    // Straight persistent form (KSpec::FUSE instances, every launched workgroup serving exactly one logical workgroup, >= 3 hidden
+    // layers): see the step loop.  The slot's rows of the current and of the next step live in two LDS arrays that swap roles.
+#ifdef HIPETS_DBG_NOSTRAIGHT
+    const bool straight = false;
+#else
+    const bool straight = kFuse && persist && ra.n_logical == (int)gridDim.x && md.n_layers >= 4;
+#endif
+    int* const rows_a = sm.rowid;
+    int* const rows_b = sm.pend + ROWS;
+    // Collect the rows `rows` holds (published by their previous owners in step t_next - 1): every thread polls its (row slot, pair)
+    // items as in the general form below, and the thread that receives a pair of state dims also writes them -- normalised exactly
+    // like build_input_impl's f64 form -- into the next step's input image: no separate input pass, two barriers less per step.
+    auto collect_straight = [&](const int t_next, const int* const rows, float* const dst) __attribute__((always_inline)) {
+        const unsigned want = ra.tag_base + (unsigned)t_next;
+        for (int base = 0; base < ROWS * NVP; base += kG * kThreads) {
+            const unsigned long long* src[kG];
+            u32x4g g[kG];
+            int gs[kG], gv[kG];
+            bool soft[kG], live[kG];
+            double nm[kG][2], ns[kG][2];
+#pragma unroll
+            for (int q = 0; q < kG; ++q) {
+                const int i = base + tid + q * kThreads;
+                gs[q] = base == 0 ? xs[q] : (i < ROWS * NVP ? i / NVP : -1);
+                gv[q] = base == 0 ? xv[q] : (i < ROWS * NVP ? i - (i / NVP) * NVP : 0);
+                soft[q] = gv[q] == NVP - 1;
+                src[q] = nullptr;
+                live[q] = false;
+                g[q] = u32x4g{0u, want, 0u, want};
+                if (gs[q] >= 0) {
+                    const int rid = rows[gs[q]];
+                    if (rid >= 0) { src[q] = ra.exchange + (size_t)rid * NV + 2 * gv[q]; live[q] = true; }
+                }
+                // the normaliser constants of the pair's two dims: requested now, used when the pair has arrived
+                const int d = soft[q] ? 0 : 2 * gv[q], d1 = min(d + 1, md.obs_dim - 1);
+                nm[q][0] = sm.nmean[d]; nm[q][1] = sm.nmean[d1];
+                ns[q][0] = sm.nstd[d]; ns[q][1] = sm.nstd[d1];
+            }
+            const long long t_poll = wall_clock64();
+            for (int spins = 0;; ++spins) {
+                static_assert(kG == 2, "the wait below names the two destinations");
+                u32x4g got[kG];
+                pair_load_issue(got[0], src[0] ? src[0] : ra.exchange);
+                pair_load_issue(got[1], src[1] ? src[1] : ra.exchange);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1])::"memory");
+                bool ready = true;
+#pragma unroll
+                for (int q = 0; q < kG; ++q)
+                    if (src[q]) {
+                        g[q] = got[q];
+                        if (got[q][1] == want && got[q][3] == want) src[q] = nullptr;
+                        else if (!soft[q]) ready = false;
+                    }
+                if (ready) break;
+                if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
+                    *ra.error_flag = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int q = 0; q < kG; ++q)
+                if (gs[q] >= 0) {
+                    if (!soft[q]) {
+                        const int d = 2 * gv[q];
+                        const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
+                        sm.state[gs[q] * md.obs_dim + d] = v0;
+                        dst[gs[q] * md.ld + lds_col(d)] = live[q] ? (float)(((double)v0 - nm[q][0]) * ns[q][0]) : 0.f;
+                        if (d + 1 < md.obs_dim) {
+                            sm.state[gs[q] * md.obs_dim + d + 1] = v1;
+                            dst[gs[q] * md.ld + lds_col(d + 1)] = live[q] ? (float)(((double)v1 - nm[q][1]) * ns[q][1]) : 0.f;
+                        }
+                    } else if (src[q]) {
+                        sm.pend[gs[q]] = 1;  // not there yet: the next tail fetches the pair
+                    } else {
+                        sm.tot[gs[q]] = __uint_as_float(g[q][0]);
+                        sm.term[gs[q]] = (int)g[q][2];
+                    }
+                }
+        }
+        HIPETS_STAMP(2, t_next - 1);  // this thread's rows have arrived
+    };
     for (int q_seq = 0; q_seq < n_seq; ++q_seq) {
         const int t = ra.t_begin + q_seq / n_serve;
         const bool more = t + 1 < ra.t_end;
@@ -1705,11 +1828,30 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             float* nxt = step_in == sm.buf0 ? sm.buf1 : sm.buf0;
             const int L = md.n_layers;
             const bool write_input = more && !persist;  // FAST form: rows stay here, the next step's input is built in place
+            // Straight persistent form (every launched workgroup serves ONE logical workgroup): everything of step t + 1 that does
+            // not depend on the rows' states is prepared while step t computes -- which rows the slot holds then (the step's keyed
+            // permutation, evaluated beside layer 1 by the wave with the lightest GEMM share), their actions (fetched behind layer 2, in LDS before
+            // the output layer, their input columns built beside it) -- so that between the output layer and the next step there
+            // is only: barrier, wait for the rows, normalise them into the input image as they arrive, barrier.
+            const bool prep_next = straight && more;
+            int* const rows_nxt = sm.rowid == rows_a ? rows_b : rows_a;
             for (int l = 0; l + 1 < L; ++l) {
                 // the raw actions of step t + 1 (requested at the top of the step) go to their LDS buffer now: visible to every
                 // thread after this layer's barrier, i.e. when the output layer starts
                 prof.mark(12);
-                if (l == L - 2 && write_input) fetch_actions_commit(t + 1, av);
+                if (l == 1 && prep_next && wave == kWaves - 1) {  // this wave's share of a hidden layer is one unit short: room for the permutation
+                    for (int s = lane; s < ROWS; s += 64) {
+                        const int j = (wg % ra.groups) * ROWS + s;
+                        rows_nxt[s] = j < ra.rows_per_domain
+                                          ? (int)perm_apply((unsigned)(domain * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t + 1]) : -1;
+                    }
+                }
+                if (l == 2 && prep_next) {  // rows_nxt is visible since layer 1's barrier
+                    act_rows = rows_nxt;
+                    compute_act_base();
+                    fetch_actions_issue(t + 1, av);
+                }
+                if (l == L - 2 && (write_input || prep_next)) fetch_actions_commit(t + 1, av);
                 mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
                 prof.mark(8);
@@ -1717,7 +1859,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             }
             // `nxt` (the output layer's would-be LDS image) is read by nobody while the output layer runs: it receives the next
             // step's model input -- action columns and zero padding from all threads here, the obs columns from the tail lanes
-            if (write_input) build_action_columns(t + 1, nxt);
+            // (FAST) / from the threads that receive the rows (straight persistent form)
+            if (write_input || prep_next) build_action_columns(t + 1, nxt);
             const float* const actn_t = sm.actn + (t & 1) * n_act;
             const unsigned handover_tg = (unsigned)(handover_tag >> 32);
             // One finished accumulator = column tile c, row tile r of the head-pair pack: this lane (group g, row j) holds
@@ -1820,10 +1963,22 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             const auto tail = make_tail(tail_prep, tail_unit, tail_finish);
             prof.mark(12);
             mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail);
-            __syncthreads();
+            // straight persistent form: what the two sides of this barrier exchange goes through LDS; the tail's write-through
+            // hand-over stores need not have been acknowledged (__syncthreads() would wait for that -- about a microsecond --
+            // before the first poll for the incoming rows is even issued; this way the two round trips overlap)
+            if (prep_next) lds_barrier();
+            else __syncthreads();
             prof.mark(8);
             HIPETS_STAMP(0, t);  // the MLP and the step's tail are done
             step_in = nxt;
+            if (prep_next) {
+                HIPETS_STAMP(1, t);
+                collect_straight(t + 1, rows_nxt, step_in);
+                sm.rowid = rows_nxt;  // the slot's rows from here on
+                __syncthreads();
+                HIPETS_STAMP(3, t);
+                continue;
+            }
             if (persist && has_next) {  // the slot's row in the next turn (the tail above was the last reader of this turn's rowid)
                 for (int s = tid; s < ROWS; s += kThreads) {
                     const int j = (v_next % ra.groups) * ROWS + s;
