@@ -169,7 +169,12 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
 int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t batch, const hipets_rollout_opts* opts,
                 float* next_obs, float* rewards, uint8_t* dones, void* stream);
 
-/* geometry the FAST kernel will use for (pop, P): workgroups and rows per group (for member_schedule) */
+/* geometry the FAST kernel will use for (pop, P): workgroups and rows per group (for member_schedule).  rows_per_group 0: the
+ * library's own choice for a DEFAULT call (hipets_rollout without injected eps / traces, the fused plans); > 0: forced.
+ * rows_per_group -1: the choice for calls that run the general kernel layout whatever the model -- hipets_step, rollouts with
+ * injected eps or traces.  The two differ only for models with a wide-output shape-specialised instance (Humanoid-v4's 376 obs
+ * dims: two row tiles per workgroup there, one in the general layout); a call of the second kind that brings its own
+ * member_schedule on such a model must size it with -1 and pass the reported row-tile count as opts->rows_per_group.        */
 int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t rows_per_group,
                          int32_t* n_workgroups, int32_t* row_tiles);
 

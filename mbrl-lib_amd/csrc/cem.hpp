@@ -14,6 +14,11 @@ struct CemDev {
     int K;             // elite_num
     float alpha, one_minus_alpha;
     int return_mean, clipped, unbiased;
+    // refit only: when set, values[i] is first formed as the mean over the P particle totals of candidate i (model_env.py:190-191;
+    // the same sequential sum and division as particle_mean_kernel, so the same bits) -- the fused plan's rollouts leave their
+    // per-row totals and this kernel reduces them, instead of a kernel launch of its own in between
+    const float* totals = nullptr;
+    int P = 0;
 };
 
 // Standard normal truncated to [-2, 2] by rejection: the stationary law of the reference's
@@ -86,6 +91,14 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     {  // one workgroup per environment: rebase every pointer to this environment's slice
         const int env = blockIdx.x;
         values += (size_t)env * p.pop;
+        if (p.totals) {
+            const float* tot = p.totals + (size_t)env * p.pop * p.P;
+            for (int i = threadIdx.x; i < p.pop; i += kRefitThreads) {
+                float s = 0.f;
+                for (int q = 0; q < p.P; ++q) s += tot[(size_t)i * p.P + q];
+                values[i] = s / (float)p.P;
+            }
+        }
         population += (size_t)env * p.pop * p.D;
         mu += (size_t)env * p.D;
         disp += (size_t)env * p.D;

@@ -152,8 +152,13 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
     return 0;
 }
 
-size_t lds_for(const hipets_engine* e, int R, int horizon) {
+// wide: the call will run a KSpec::WIDE instance (launch.hpp wide_model + lean_call): hidden-width activation buffers, the input
+// image with its own stride in buf0
+size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
     const ModelDev& md = e->md;
+    if (wide)
+        return rollout_smem_bytes(kTile * R, lean_ld(md.hidC, md.hidC), md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, horizon, false,
+                                  md.lv_rows, md.ld_in);
     return rollout_smem_bytes(kTile * R, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, horizon,
                               md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows);
 }
@@ -167,13 +172,14 @@ int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (w
     return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
 }
 
-int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon) {
+int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon, bool wide = false) {
     if (forced > 0) return forced;
     const int C = e->md.hidC;
     int best = 1;
     double best_cost = 1e300;
     for (int R = 1; R <= kMaxR; ++R) {
-        if (lds_for(e, R, horizon) > e->lds_max) break;
+        if (lds_for(e, R, horizon, wide) > e->lds_max) break;
+        if (wide && R > 2) break;  // WIDE instances exist for R = 1, 2 (rollout_inst.inc)
         const long long groups = (tiles_total_per_slice + R - 1) / R;
         const long long nwg = groups * slices;
         const long long rounds = (nwg + e->num_cu - 1) / e->num_cu;
@@ -244,7 +250,7 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     }
     if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
     const long long tiles = (pop + kTile - 1) / kTile;
-    const int R = choose_R(e, tiles, P, 0, H);
+    const int R = choose_R(e, tiles, P, 0, H, wide_model(md) && n_env == 1);  // the fused plans' rollouts are lean calls unless batched
     const int nwg = (int)((tiles + R - 1) / R) * P;
     if (nwg > 8000) return 0;  // the rollout reports the error
     if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
@@ -514,6 +520,8 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
         ld = ldb / 4;
     }
     md.ld = ld;
+    md.ld_in = md.Kp0;  // KSpec::WIDE instances: the model-input image's own row stride
+    while (md.ld_in % 64 != 8) md.ld_in += 4;
     if (rollout_smem_bytes(kTile, md.ld, md.obs_dim, md.act_dim, md.in_dim, md.out_dim, md.out_total, 64,
                            md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows) > e->lds_max)
         return fail("model too wide for LDS (ld=%d)", md.ld);
@@ -592,10 +600,11 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
                          int32_t* n_workgroups, int32_t* row_tiles) {
     if (!e || !e->has_model) return fail("engine has no model");
     if (pop < 1 || P < 1) return fail("bad pop/P");
-    if (rows_per_group < 0 || rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
+    if (rows_per_group < -1 || rows_per_group > kMaxR) return fail("rows_per_group outside [-1, %d]", kMaxR);
     const long long tiles = (pop + kTile - 1) / kTile;
-    const int R = choose_R(e, tiles, P, rows_per_group, horizon);
-    if (lds_for(e, R, horizon) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
+    const bool wide = rows_per_group >= 0 && rows_per_group <= 2 && wide_model(e->md);  // a default call runs the WIDE instance there
+    const int R = choose_R(e, tiles, P, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide);
+    if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
     const long long groups = (tiles + R - 1) / R;
     if (n_workgroups) *n_workgroups = (int)(groups * P);
     if (row_tiles) *row_tiles = R;
@@ -626,7 +635,7 @@ namespace {
 int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
                  const hipets_rollout_opts* o, float* returns, void* stream, const int* presched) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
-    if (!actions || !o || !returns) return fail("null argument");
+    if (!actions || !o) return fail("null argument");  // (returns == nullptr: internal callers that fold the particle mean)
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
     if (e->error_flag && *e->error_flag) {  // raised by an EARLIER launch: its returns were garbage
         *e->error_flag = 0;
@@ -687,8 +696,16 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         }
         const int rpd = expectation ? (int)B : (slots ? o->rows_per_member : (int)(B / domains));
         const long long tiles = (rpd + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, domains, o->rows_per_group, H);
-        const size_t lds = lds_for(e, R, H);
+        bool wide = false;
+        if (device && wide_model(md)) {  // will the launcher pick the WIDE instance?  (its lean_call on what `ra` is going to hold)
+            RolloutArgs probe = ra;
+            probe.eps = nullptr;
+            probe.use_philox = o->no_sample ? 0 : 1;
+            wide = lean_call(md, probe) && o->rows_per_group <= 2;
+        }
+        ra.wide_lds = wide ? 1 : 0;
+        const int R = choose_R(e, tiles, domains, o->rows_per_group, H, wide);
+        const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
         // rows change workgroups between steps only when a fresh permutation is drawn per step: one launch per step then
@@ -791,15 +808,22 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         }
     } else if (o->mode == HIPETS_MODE_FAST) {
         const long long tiles = (pop + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, P, o->rows_per_group, H);
-        const size_t lds = lds_for(e, R, H);
+        ra.eps = o->fast_eps;
+        ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
+        // (a caller-sized member schedule follows hipets_fast_geometry, which reports the general layout's geometry)
+        const bool wide = wide_model(md) && lean_call(md, ra) && o->rows_per_group <= 2;
+        if (!wide && wide_model(md) && o->member_schedule && o->rows_per_group == 0)
+            return fail("this call runs the general kernel layout (injected eps / traces / generic_kernel) on a model whose default geometry is "
+                        "the wide-output instance's: size member_schedule with hipets_fast_geometry(rows_per_group = -1) and pass its row-tile "
+                        "count as opts->rows_per_group");
+        ra.wide_lds = wide ? 1 : 0;
+        const int R = choose_R(e, tiles, P, o->rows_per_group, H, wide);
+        const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
         const int nwg = groups * P;
         if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d); shard the population", nwg);
         ra.groups = groups;
-        ra.eps = o->fast_eps;
-        ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
         if (md.propagation != HIPETS_PROP_EXPECTATION) {
             if (o->member_schedule) {
                 ra.schedule = o->member_schedule;
@@ -820,6 +844,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     } else {
         return fail("unknown rollout mode %d", o->mode);
     }
+    if (!returns) return 0;  // the caller reduces e->totals over the particles itself (hipets_plan_cem: inside the refit kernel)
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
     return 0;
@@ -1143,11 +1168,15 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
                            e->population.as<float>());
         HCHECK(hipGetLastError());
         ro.stream_id = sid;
-        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, e->values.as<float>(), stream,
+        // the particle mean of the returns (model_env.py:190-191) happens inside the refit kernel: one launch less per iteration
+        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, nullptr, stream,
                          sched ? sched + (size_t)i * sched_stride : nullptr))
             return 1;
         int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * n_env * c.K : nullptr;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+        CemDev cr = c;
+        cr.totals = e->totals.as<float>();
+        cr.P = P;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, cr, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());

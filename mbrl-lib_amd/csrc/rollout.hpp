@@ -70,6 +70,7 @@ struct ModelDev {
     long long wmember;  // floats per member (packed weights)
     int bmember;        // floats per member (padded biases)
     int ld;             // LDS activation row stride in floats (== 8 mod 64)
+    int ld_in;          // KSpec::WIDE instances: row stride of the model-input image (>= Kp0, == 8 mod 64); the hidden activations use KSpec::LD
     const float* w;
     const float* b;
     const double* norm_mean;
@@ -110,6 +111,7 @@ struct RolloutArgs {
     const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
     int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
     int generic_only;          // never pick a shape-specialised (lean) kernel instance (hipets_rollout_opts.generic_kernel)
+    int wide_lds;              // the host sized the LDS (and chose R) for the KSpec::WIDE layout: the launcher runs that instance or fails
     // DEVICE mode, persistent form (all workgroups co-resident, ONE launch for the horizon): rows change workgroups every step
     // through `exchange`, a [B][obs_dim + 2] table of 8-byte {value bits, step tag} granules (state dims, running total,
     // terminated flag).  A granule is written by ONE write-through (sc1) 8-byte store and polled with sc1 loads until its
@@ -284,12 +286,14 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC_rt,
                                           const int tail_steps, const int c_first, const Extras ex,
                                           const bool apply_act, const int act, const float slope, const int lane,
-                                          Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr) {
+                                          Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr,
+                                          const int ldi_rt = 0) {
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
     f32x4 acc[CTn][R];
     f32x4 accx[EXn];
     const int ld = LD > 0 ? LD : ld_rt;
+    const int ldi = ldi_rt > 0 ? ldi_rt : ld;  // row stride of `in` when it differs from the output's (KSpec::WIDE: the model-input image)
     const int KC = KCS > 0 ? KCS : KC_rt;
 
     const int exc[kMaxExtras] = {ex.c0, ex.c1, ex.c2, ex.c3};
@@ -304,10 +308,10 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
         wxoff[e] = (unsigned)((exc[e] * KC * 64 + lane) * 16);
-        axoff[e] = exr[e] * 16 * ld;
+        axoff[e] = exr[e] * 16 * ldi;
     }
     const char* Wb = reinterpret_cast<const char*>(W);
-    const float* ap = in + (lane & 15) * ld + 4 * (lane >> 4);
+    const float* ap = in + (lane & 15) * ldi + 4 * (lane >> 4);
     // biases of this lane's columns: loaded before the k loop so their latency hides behind it
     f32x4 bv[CTn], bvx[EXn];
     if constexpr (PRE) {
@@ -352,7 +356,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         for (int e = 0; e < EX; ++e) f.bx[e] = *reinterpret_cast<const f32x4*>(Wk + wxoff[e]);
 #endif
 #pragma unroll
-        for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld + kk * 16);
+        for (int r = 0; r < R; ++r) f.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ldi + kk * 16);
 #pragma unroll
         for (int e = 0; e < EX; ++e) f.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + kk * 16);
     };
@@ -421,7 +425,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         if (i < CT) g.b[i < CT ? i : 0] = *reinterpret_cast<const f32x4*>(Wb + (size_t)kk * 1024 + woff[i < CT ? i : 0]);
         else if (i < CT + EX) g.bx[i - CT] = *reinterpret_cast<const f32x4*>(Wb + (size_t)kk * 1024 + wxoff[i - CT]);
 #endif
-        else if (CT > 0 && i < CT + EX + R) g.a[i - CT - EX] = *reinterpret_cast<const f32x4*>(ap + (i - CT - EX) * 16 * ld + kk * 16);
+        else if (CT > 0 && i < CT + EX + R) g.a[i - CT - EX] = *reinterpret_cast<const f32x4*>(ap + (i - CT - EX) * 16 * ldi + kk * 16);
         else {
             const int e = i - CT - EX - (CT > 0 ? R : 0);
             g.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e] + kk * 16);
@@ -512,7 +516,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 #pragma unroll
         for (int e = 0; e < EX; ++e) f0.bx[e] = pre->bx[e];
 #pragma unroll
-        for (int r = 0; r < R; ++r) f0.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ld);
+        for (int r = 0; r < R; ++r) f0.a[r] = *reinterpret_cast<const f32x4*>(ap + r * 16 * ldi);
 #pragma unroll
         for (int e = 0; e < EX; ++e) f0.ax[e] = *reinterpret_cast<const f32x4*>(ap + axoff[e]);
     } else {
@@ -610,14 +614,18 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
             compute_tail(f0);
         }
     }
-    FusedSlot slots[CT * R + EX > 0 ? CT * R + EX : 1];
-    if constexpr (!std::is_same<TL, NoTail>::value) {  // the tail's LDS loads of ALL units, in flight while the matrix pipe drains
+    // the fused tail runs over the wave's units in groups of at most kTailGroup: within a group the LDS loads of ALL its units are
+    // issued first (prep), then the arithmetic (unit); the slots of one group are dead before the next starts (a wave of a
+    // 47-tile output layer holds 6-8 units per pass: all their slots at once would not fit the arch VGPRs)
+    constexpr int kNUt = CT * R + EX;
+    constexpr int kTailGroup = 4;
+    FusedSlot slots[kTailGroup];
+    auto unit_c = [&](const int u) __attribute__((always_inline)) { return u < CT * R ? c_first + kWaves * (u / R) : exc[(u >= CT * R && u < kNUt) ? u - CT * R : 0]; };
+    auto unit_r = [&](const int u) __attribute__((always_inline)) { return u < CT * R ? u % R : exr[(u >= CT * R && u < kNUt) ? u - CT * R : 0]; };
+    if constexpr (!std::is_same<TL, NoTail>::value) {  // the first group's LDS loads: in flight while the matrix pipe drains
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < R; ++r) tl->prep(slots[ct * R + r], c_first + kWaves * ct, r);
-#pragma unroll
-        for (int e = 0; e < EX; ++e) tl->prep(slots[CT * R + e], exc[e], exr[e]);
+        for (int k = 0; k < kTailGroup; ++k)
+            if (k < kNUt) tl->prep(slots[k < kNUt ? k : 0], unit_c(k), unit_r(k));
     }
     if constexpr (kSplit) {
         mfma_drain();
@@ -638,12 +646,23 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     prof.mark(11);
     if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
     if constexpr (!std::is_same<TL, NoTail>::value) {
+        // (constant trip counts on both levels: every slot / accumulator index must be a constant after unrolling)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int g = 0; g < (kNUt + kTailGroup - 1) / kTailGroup; ++g) {
+            if (g > 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) tl->unit(slots[ct * R + r], acc[ct][r], c_first + kWaves * ct, r);
+                for (int k = 0; k < kTailGroup; ++k) {
+                    const int u = g * kTailGroup + k;
+                    if (u < kNUt) tl->prep(slots[k], unit_c(u), unit_r(u));
+                }
+            }
 #pragma unroll
-        for (int e = 0; e < EX; ++e) tl->unit(slots[CT * R + e], accx[e], exc[e], exr[e]);
+            for (int k = 0; k < kTailGroup; ++k) {
+                const int u = g * kTailGroup + k;
+                if (u < CT * R) tl->unit(slots[k], acc[(u < CT * R ? u : 0) / R][(u < CT * R ? u : 0) % R], unit_c(u), unit_r(u));
+                else if (u < kNUt) tl->unit(slots[k], accx[(u >= CT * R && u < kNUt) ? u - CT * R : 0], unit_c(u), unit_r(u));
+            }
+        }
         tl->finish();
         prof.mark(9);  // the fused tail is booked as the "sample" phase
         return;
@@ -735,7 +754,8 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 template <int R, int ACT = -1, int CS = -1, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
-                                          const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr) {
+                                          const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr,
+                                          const int ldi = 0) {
     static_assert(std::is_same<TL, NoTail>::value || CS >= 0, "a fused tail needs a shape-specialised op");
     const int KC = lm.Kp / kKChunk;
     // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
@@ -750,23 +770,29 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         ex.c3 = kWaves * full + (wave + 3 * kWaves) / R; ex.r3 = (wave + 3 * kWaves) % R;
         constexpr int passes = full > kMaxCT ? (full - 1) / kMaxCT : 0;  // whole passes of kMaxCT tiles before the last one
         constexpr int last = full - passes * kMaxCT;                      // 0 .. kMaxCT column tiles ride with the extras
+        if constexpr (std::is_same<TL, NoTail>::value) {
 #pragma unroll
-        for (int p = 0; p < passes; ++p)
-            wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl);
+            for (int p = 0; p < passes; ++p)
+                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
+        } else {  // with a fused tail inlined per unit the body is large: ONE copy, a real loop over the passes
+#pragma nounroll
+            for (int p = 0; p < passes; ++p)
+                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
+        }
         const int c_first = wave + kWaves * kMaxCT * passes;
         // the nu leftover units are dealt round-robin: waves below nu % kWaves hold one more than the others
         constexpr int lo = nu / kWaves, hi = (nu + kWaves - 1) / kWaves;
         static_assert(!PRE || passes == 0, "cross-layer prefetch needs the op to fit one wave_gemm per wave");
         if constexpr (lo == hi) {
             if constexpr (last > 0 || lo > 0)
-                wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
+                wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
             else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);  // nothing to compute here: still fetch for the next op
         } else {
             if (wave < nu % kWaves) {
-                wave_gemm<R, last, hi, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
+                wave_gemm<R, last, hi, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
             } else {
                 if constexpr (last > 0 || lo > 0)
-                    wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl);
+                    wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
                 else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
             }
         }
@@ -1043,7 +1069,15 @@ constexpr int lean_ld(int hidc, int outc) {
 template <int ACT_, int HIDC_ = -1, int OUTC_ = -1, int NORM_ = -1, int OBSP_ = -1, int REW_ = -1, int TERM_ = -1, int KMODE_ = -1, int PREC_ = 0,
           int FUSE_ = 0>
 struct KSpec {
-    static constexpr int LD = (HIDC_ >= 0 && PREC_ == HIPETS_PREC_F32) ? lean_ld(HIDC_, OUTC_) : -1;  // compile-time LDS row stride (fp32 lean instances)
+    // WIDE (fused fp32 instances whose output layer is wider than kSplMaxTiles column tiles -- cfg4': 47): no LDS image of the outputs
+    // exists at all, so the two activation buffers hold hidden activations only (row stride for HIDC tiles) and the model-input
+    // image -- wider than a hidden layer there: 393 columns -- lives in buf0 with its own run-time stride (ModelDev::ld_in).
+    // 4.4 KB of LDS per row instead of 7.6: two row tiles per workgroup fit where one did.
+#ifndef HIPETS_WIDE_FUSE
+#define HIPETS_WIDE_FUSE 1
+#endif
+    static constexpr bool WIDE = HIPETS_WIDE_FUSE && FUSE_ != 0 && HIDC_ >= 0 && PREC_ == HIPETS_PREC_F32 && OUTC_ > kSplMaxTiles;
+    static constexpr int LD = (HIDC_ >= 0 && PREC_ == HIPETS_PREC_F32) ? lean_ld(HIDC_, WIDE ? HIDC_ : OUTC_) : -1;  // compile-time LDS row stride (fp32 lean instances)
     static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
     static constexpr int PREC = PREC_;  // HIPETS_PREC_F32 (fp32 MFMA) or HIPETS_PREC_BF16X3 (lean instances only)
     static constexpr bool LEAN = HIDC_ >= 0;
@@ -1052,7 +1086,8 @@ struct KSpec {
     // normalised model input happen in registers in the output layer's own barrier interval (5 barriers per step instead
     // of 7, no LDS round trip of the 2 x out_dim outputs).  Needs reward / termination forms that read state dims 0..3 only.
     // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
-    static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && OUTC_ <= kSplMaxTiles;
+    static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && (OUTC_ <= kSplMaxTiles || WIDE);
+    static constexpr bool SPL_OUT = OUTC_ >= 0 && OUTC_ <= kSplMaxTiles;  // the output layer sums even / odd k-steps separately (wave_gemm SPL)
     static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE) &&
                             (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID)),
                   "fused tail: the reward / termination lane sees dims 0..3 of its row");
@@ -1127,7 +1162,7 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
         // puts v_mov copies straight behind asm MFMAs -- which it believes complete at once (wave_gemm, "drain_all") -- and the
         // interleaved + unrolled build returned wrong sums (caught by the cfg5 parity tests); R = 1 measured 1 % slower unrolled.
         constexpr int kHidChunks = (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1;
-        if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, S::WIDE ? md.ld_in : 0);
         else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
         else linear_op<R, S::ACT, S::OUTC, false, NoTail, S::LD, (S::OUTC <= kSplMaxTiles), kHidChunks>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
     } else {
@@ -1145,7 +1180,7 @@ __device__ __forceinline__ void mlp_output_layer_fused(const ModelDev& md, const
     const LayerMeta lm = lmeta[md.n_layers - 1];
     const float* W = md.w + (size_t)member * md.wmember + lm.woff_pairs;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff_pairs;
-    linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, true, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
+    linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
 }
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
@@ -1260,10 +1295,11 @@ struct RolloutSmem {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// ld0 > 0: buf0 has its own row stride (KSpec::WIDE: the model-input image), buf1 uses `ld`
 __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_dim, int act_dim, int in_dim, int out_dim,
-                                                     int out_total, int horizon, bool expectation, int lv_rows = 1) {
+                                                     int out_total, int horizon, bool expectation, int lv_rows = 1, int ld0 = 0) {
     size_t n = 0;
-    n += 2 * align16((size_t)rows * ld * 4);
+    n += align16((size_t)rows * (ld0 > 0 ? ld0 : ld) * 4) + align16((size_t)rows * ld * 4);
     n += align16((size_t)rows * obs_dim * 4);
     n += align16((size_t)2 * rows * act_dim * 4);
     n += 4 * align16((size_t)rows * 4) + align16((size_t)2 * rows * 4);
@@ -1287,7 +1323,7 @@ __device__ __forceinline__ float softplus_fast(float x) {
     return x > 20.0f ? x : y;
 }
 
-template <int R> struct MinWaves { static constexpr int value = MinWavesOf<R>::value; };
+template <int R, class S> struct MinWaves { static constexpr int value = S::WIDE ? 1 : MinWavesOf<R>::value; };  // (WIDE: the LDS admits one workgroup per CU anyway)
 
 // S = KSpec<...>: the compile-time facts of this instance (generic: only the activation may be fixed; lean: the whole shape).
 // Profiling build only (-DHIPETS_STEP_TRACE, profiles/handover_trace.py): wall-clock stamps (100 MHz, chip-wide) of every
@@ -1302,7 +1338,7 @@ template <int R> struct MinWaves { static constexpr int value = MinWavesOf<R>::v
 #endif
 
 template <int R, class S>
-__global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
+__global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_kernel(const ModelDev md, const RolloutArgs ra) {
     constexpr int ROWS = kTile * R;
     constexpr bool kLean = S::LEAN;
     constexpr bool kB3 = S::PREC == HIPETS_PREC_BF16X3;  // operands as three bf16 pieces on the bf16 matrix pipe (lean instances)
@@ -1324,28 +1360,34 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     const bool deterministic = kLean ? false : md.deterministic != 0;
     float* const trace_next_obs = kLean ? nullptr : ra.trace_next_obs;
     float* const trace_rewards = kLean ? nullptr : ra.trace_rewards;
+    const int ld_k = S::LD > 0 ? S::LD : md.ld;  // the LDS row stride: a compile-time fact in the shape-specialised fp32 instances
+    constexpr bool kWide = S::WIDE;
+    const int ld_in = kWide ? md.ld_in : ld_k;    // row stride of the model-input image (buf0 in the WIDE instances, see KSpec)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RolloutSmem sm;
     {
+        // sections whose size follows from ROWS and the row stride first: in a shape-specialised instance (compile-time stride) their
+        // addresses are constants -- immediate offsets in the LDS instructions instead of a live SGPR each (the DEVICE instance
+        // of cfg2 spills > 200 scalars); the sections sized by the model's run-time dimensions follow
         char* p = smem;
-        sm.buf0 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.ld * 4);
-        sm.buf1 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.ld * 4);
-        sm.state = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.obs_dim * 4);
-        sm.actn = reinterpret_cast<float*>(p); p += align16((size_t)2 * ROWS * md.act_dim * 4);
+        sm.buf0 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * (kWide ? md.ld_in : ld_k) * 4);
+        sm.buf1 = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * ld_k * 4);
         sm.tot = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * 4);
         sm.lrew = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * 4);
         sm.term = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
         sm.rowid = reinterpret_cast<int*>(p); p += align16((size_t)ROWS * 4);
         sm.pend = reinterpret_cast<int*>(p); p += align16((size_t)2 * ROWS * 4);
+        sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
+        sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
+        sm.dump = reinterpret_cast<float*>(p); p += 16;
+        sm.state = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.obs_dim * 4);
+        sm.actn = reinterpret_cast<float*>(p); p += align16((size_t)2 * ROWS * md.act_dim * 4);
         sm.nmean = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
         sm.nstd = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
         sm.minlv = reinterpret_cast<float*>(p); p += align16((size_t)md.lv_rows * md.out_dim * 4);
         sm.maxlv = reinterpret_cast<float*>(p); p += align16((size_t)md.lv_rows * md.out_dim * 4);
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
-        sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
-        sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
-        sm.dump = reinterpret_cast<float*>(p); p += 16;
         sm.expacc = reinterpret_cast<float*>(p);
     }
     const int tid = threadIdx.x;
@@ -1430,7 +1472,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
         // bf16x3: the k chunks are 32 wide, the column tiles 16: the last chunk of a 13-tile layer ends in 16 columns no epilogue
         // ever writes.  Their weights are zero, but 0 x (whatever bits LDS holds) may be NaN: clear both activation buffers once.
         f32x4* z = reinterpret_cast<f32x4*>(sm.buf0);
-        const int n16 = (int)(2 * align16((size_t)ROWS * md.ld * 4) / 16);
+        const int n16 = (int)(2 * align16((size_t)ROWS * ld_k * 4) / 16);
         for (int i = tid; i < n16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // ---- per-dimension constants -> LDS, and the rows' initial state / totals / flags / first actions: EVERY global load of the
@@ -1625,12 +1667,12 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             if constexpr (kB3) {  // three bf16 pieces per value, in the B-operand layout of wave_gemm_b3
                 u32x2 pc[3];
                 split3x4(f32x4{v[0], v[1], v[2], v[3]}, pc);
-                char* row = reinterpret_cast<char*>(dst) + (size_t)s * md.ld * 4;
+                char* row = reinterpret_cast<char*>(dst) + (size_t)s * ld_in * 4;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(row + b3_offset(4 * cq, p)) = pc[p];
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[s * md.ld + lds_col(4 * cq + q)] = v[q];
+                for (int q = 0; q < 4; ++q) dst[s * ld_in + lds_col(4 * cq + q)] = v[q];
             }
         }
     };
@@ -1659,7 +1701,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
     // This thread's column of those (<= 16 action + padding columns, the usual case): column obs_in + (tid & 15), rows tid / 16 + 16 q --
     // no division, the column's normaliser constants and LDS position fixed for the launch.
     const int bac_c = md.obs_in + (tid & 15);
-    const bool bac_fast = kFuse && Kp0 - md.obs_in <= 16;
+    const bool bac_fast = kFuse && !kWide && Kp0 - md.obs_in <= 16;
     const bool bac_live = bac_fast && bac_c < md.in_dim;  // an action column (else zero padding, or beyond Kp0: nothing to write)
     double bac_nm = 0.0, bac_ns = 0.0;  // read from LDS once the prologue has put the constants there (below)
     const int bac_pos = lds_col(min(bac_c, Kp0 - 1));
@@ -1683,7 +1725,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
 #pragma unroll
                 for (int q = 0; q < kPasses; ++q) {
                     const int s = r0 + kRowsPerPass * q;
-                    if (s < ROWS) dst[s * md.ld + bac_pos] = (bac_live && rid[q] >= 0) ? (float)(((double)x[q] - bac_nm) * bac_ns) : 0.f;
+                    if (s < ROWS) dst[s * ld_in + bac_pos] = (bac_live && rid[q] >= 0) ? (float)(((double)x[q] - bac_nm) * bac_ns) : 0.f;
                 }
             }
             return;
@@ -1696,7 +1738,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 const float x = actn_t[s * md.act_dim + (c - md.obs_in)];
                 v = (float)(((double)x - sm.nmean[c]) * sm.nstd[c]);  // KSpec::FUSE instances: f64 normaliser (static_assert in KSpec)
             }
-            dst[s * md.ld + lds_col(c)] = v;
+            dst[s * ld_in + lds_col(c)] = v;
         }
     };
 
@@ -1796,10 +1838,10 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                         const int d = 2 * gv[q];
                         const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
                         sm.state[gs[q] * md.obs_dim + d] = v0;
-                        dst[gs[q] * md.ld + lds_col(d)] = live[q] ? (float)(((double)v0 - nm[q][0]) * ns[q][0]) : 0.f;
+                        dst[gs[q] * ld_in + lds_col(d)] = live[q] ? (float)(((double)v0 - nm[q][0]) * ns[q][0]) : 0.f;
                         if (d + 1 < md.obs_dim) {
                             sm.state[gs[q] * md.obs_dim + d + 1] = v1;
-                            dst[gs[q] * md.ld + lds_col(d + 1)] = live[q] ? (float)(((double)v1 - nm[q][1]) * ns[q][1]) : 0.f;
+                            dst[gs[q] * ld_in + lds_col(d + 1)] = live[q] ? (float)(((double)v1 - nm[q][1]) * ns[q][1]) : 0.f;
                         }
                     } else if (src[q]) {
                         sm.pend[gs[q]] = 1;  // not there yet: the next tail fetches the pair
@@ -1827,7 +1869,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             float* cur = step_in;
             float* nxt = step_in == sm.buf0 ? sm.buf1 : sm.buf0;
             const int L = md.n_layers;
-            const bool write_input = more && !persist;  // FAST form: rows stay here, the next step's input is built in place
+            const bool write_input = more && !persist && !kWide;  // FAST form: rows stay here, the next step's input is built in place
+            const bool wide_fast_next = kWide && more && !persist;  // WIDE: buf0 is the input image AND an activation buffer: the input is built after the step
             // Straight persistent form (every launched workgroup serves ONE logical workgroup): everything of step t + 1 that does
             // not depend on the rows' states is prepared while step t computes -- which rows the slot holds then (the step's keyed
             // permutation, evaluated beside layer 1 by the wave with the lightest GEMM share), their actions (fetched behind layer 2, in LDS before
@@ -1851,7 +1894,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                     compute_act_base();
                     fetch_actions_issue(t + 1, av);
                 }
-                if (l == L - 2 && (write_input || prep_next)) fetch_actions_commit(t + 1, av);
+                if (l == L - 2 && (write_input || prep_next || wide_fast_next)) fetch_actions_commit(t + 1, av);
                 mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
                 __syncthreads();
                 prof.mark(8);
@@ -1860,7 +1903,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             // `nxt` (the output layer's would-be LDS image) is read by nobody while the output layer runs: it receives the next
             // step's model input -- action columns and zero padding from all threads here, the obs columns from the tail lanes
             // (FAST) / from the threads that receive the rows (straight persistent form)
-            if (write_input || prep_next) build_action_columns(t + 1, nxt);
+            if (write_input || (prep_next && !kWide)) build_action_columns(t + 1, nxt);
             const float* const actn_t = sm.actn + (t & 1) * n_act;
             const unsigned handover_tg = (unsigned)(handover_tag >> 32);
             // One finished accumulator = column tile c, row tile r of the head-pair pack: this lane (group g, row j) holds
@@ -1909,8 +1952,8 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 sm.state[okA ? s * md.obs_dim + d0 : (int)(sm.dump - sm.state)] = vA;
                 sm.state[okB ? s * md.obs_dim + d0 + 1 : (int)(sm.dump - sm.state) + 1] = vB;
                 if (write_input) {  // wave-uniform; build_input_impl's f64 form, OBSP none: input column d = obs dim d
-                    nxt[okA ? s * md.ld + lds_col(d0) : (int)(sm.dump - nxt) + 2] = (float)(((double)vA - nmA) * nsA);
-                    nxt[okB ? s * md.ld + lds_col(d0 + 1) : (int)(sm.dump - nxt) + 3] = (float)(((double)vB - nmB) * nsB);
+                    nxt[okA ? s * ld_k + lds_col(d0) : (int)(sm.dump - nxt) + 2] = (float)(((double)vA - nmA) * nsA);
+                    nxt[okB ? s * ld_k + lds_col(d0 + 1) : (int)(sm.dump - nxt) + 3] = (float)(((double)vB - nmB) * nsB);
                 }
                 const unsigned pubA = okA ? __float_as_uint(vA) : 0u, pubB = okB ? __float_as_uint(vB) : 0u;
                 // persistent DEVICE form: the row's next owner waits for these values.  Under a real (divergent) predicate: redirecting
@@ -1970,9 +2013,14 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
             else __syncthreads();
             prof.mark(8);
             HIPETS_STAMP(0, t);  // the MLP and the step's tail are done
-            step_in = nxt;
+            step_in = kWide ? sm.buf0 : nxt;
+            if (wide_fast_next) {  // the tail wrote the new states; the input image of step t + 1 from them (buf0 is free again)
+                build_input(t + 1, step_in);
+                __syncthreads();
+            }
             if (prep_next) {
                 HIPETS_STAMP(1, t);
+                if (kWide) build_action_columns(t + 1, step_in);  // (not beside the output layer: buf0 may be the buffer it reads)
                 collect_straight(t + 1, rows_nxt, step_in);
                 sm.rowid = rows_nxt;  // the slot's rows from here on
                 __syncthreads();
@@ -2029,7 +2077,7 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                 if (expectation) {  // gaussian_mlp.py:213-215: mean over members of mean AND (clamped) logvar
                     for (int i = tid; i < ROWS * md.out_total; i += kThreads) {
                         const int s = i / md.out_total, c = i % md.out_total;
-                        float v = result[s * md.ld + c];
+                        float v = result[s * ld_k + c];
                         if (!deterministic && c >= md.out_dim) {
                             const int d = c - md.out_dim;
                             const int bd = (lv_rows > 1 ? member * md.out_dim : 0) + d;
@@ -2076,9 +2124,9 @@ __global__ __launch_bounds__(kThreads, MinWaves<R>::value) void rollout_kernel(c
                             mean = sm.expacc[s * md.out_total + d] / (float)md.M;
                             if constexpr (MODE != 0) lv = sm.expacc[s * md.out_total + md.out_dim + d] / (float)md.M;
                         } else {
-                            mean = result[s * md.ld + d];
+                            mean = result[s * ld_k + d];
                             if constexpr (MODE != 0) {
-                                lv = result[s * md.ld + md.out_dim + d];
+                                lv = result[s * ld_k + md.out_dim + d];
                                 lv = lvmax[d] - softplus_fast(lvmax[d] - lv);  // gaussian_mlp.py:152
                                 lv = lvmin[d] + softplus_fast(lv - lvmin[d]);  // :153
                             }

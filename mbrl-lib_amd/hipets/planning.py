@@ -243,7 +243,7 @@ class ModelEnv:
             if self.mode == "exact":
                 self._fixed_perm = torch.randperm(B).to(self.device)
             else:
-                nwg, _ = self.engine.fast_geometry(B, 1, 1)
+                nwg, _ = self.engine.fast_geometry(B, 1, 1, -1)  # hipets_step runs the general kernel layout
                 self._fixed_schedule = self.engine.fast_schedule(1, nwg, self.seed, self._steps + 1).contiguous()
         return {"obs": obs, "propagation_indices": self._fixed_perm}
 
@@ -346,7 +346,7 @@ class UnfusedTrajectoryEvalFn:
         terminated = torch.zeros(pop * P, 1, dtype=torch.bool, device=self.device)
         schedule = None
         if self.spec.propagation == "fixed_model":  # TS-infinity: one member map for the whole horizon (model.py:404-407)
-            nwg, _ = self.engine.fast_geometry(pop * P, 1, 1)
+            nwg, _ = self.engine.fast_geometry(pop * P, 1, 1, -1)  # hipets_step runs the general kernel layout
             schedule = self.engine.fast_schedule(1, nwg, self.seed, self.calls * 4096).contiguous()
         for t in range(H):
             act = torch.repeat_interleave(a_seq[:, t, :], P, dim=0).contiguous()  # model_env.py:179-182

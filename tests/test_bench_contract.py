@@ -1,4 +1,4 @@
-"""The bench line the repository ships (profiles/r2_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
+"""The bench line the repository ships (profiles/r3_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
 contract and is internally consistent: the roofline block follows from the algorithmic FLOP count and the measured launch
 time, `value` from the plan time, the metric / workload are BASELINE.json's.  (CPU test: reads committed files only.)"""
 import json
@@ -10,7 +10,7 @@ from conftest import ROOT
 
 
 def _line():
-    return json.load(open(os.path.join(ROOT, "profiles", "r2_bench_line.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r3_bench_line.json")))
 
 
 def test_contract_keys_and_types():
@@ -46,11 +46,11 @@ def test_roofline_block_is_consistent():
 
 
 def test_rocprof_summary_agrees_with_the_live_measurement():
-    """profiles/r2_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
+    """profiles/r3_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
     import csv
 
     r = _line()["roofline"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_kernel_stats_device.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r3_kernel_stats_device.csv"))))
     roll = [x for x in rows if "rollout_kernel" in x["Name"]]
     assert roll, "no rollout kernel in the committed rocprofv3 statistics"
     avg_ms = float(roll[0]["AverageNs"]) * 1e-6

@@ -392,3 +392,30 @@ def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=True)
     assert torch.equal(a, b)
     assert torch.isfinite(a).all()
+
+
+WIDE_CASES = [SIZES[10], SIZES[11],
+              # cfg4' at its first iCEM iteration's batch: 20 020 rows = 4 004 per member = 126 two-tile workgroups per member, 630
+              # logical workgroups on 256 CUs: the turn-based persistent form
+              (376, 17, 1001, 20, 2, dict(ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid"))]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}")
+def test_wide_output_instance_equals_the_generic_kernel_bitwise(engine, case):
+    """cfg4' (Humanoid-v4: 752 output columns) runs a KSpec::WIDE instance: the output layer's accumulators go straight into the
+    step's tail in passes of 3 column tiles, no LDS image of the outputs, hidden-width activation buffers, the 393-wide model input
+    with its own row stride -- which is what lets TWO row tiles per workgroup fit the LDS (the general layout holds one).  DEVICE
+    mode: the permutation decides which member a row visits, not the workgroup geometry, so the instance (R = 2) and the generic
+    kernel (R = 1) must return the same bits; FAST mode's member schedule is per workgroup, so there both run R = 1."""
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    _, r = engine.fast_geometry(pop, P, H)
+    _, r_general = engine.fast_geometry(pop, P, H, -1)
+    assert r_general == 1 and r in (1, 2)  # (the cost model may still prefer one tile: FAST at pop 1001 runs 5 rounds of R = 1 against 3 of R = 2)
+    a = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=11, stream_id=3)
+    b = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=11, stream_id=3, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    a = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=11, stream_id=3, rows_per_group=1)
+    b = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=11, stream_id=3, rows_per_group=1, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
