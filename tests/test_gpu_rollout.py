@@ -394,6 +394,19 @@ def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case
     assert torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("rows_per_group", [2, 4])
+def test_cfg4_instances_for_the_decaying_icem_populations_equal_the_generic_kernel_bitwise(engine, rows_per_group, mode):
+    """iCEM's population decays (cfg4: 1036, 805, 630, 497, 358 candidates) and the cost model gives the later iterations two or
+    four row tiles per workgroup instead of three: the cfg4 shape has shape-specialised instances for those tile counts too."""
+    obs, act, pop, P, H, mkw = SIZES[3]
+    om, actions, s0, _, _ = _random_case(obs, act, 497, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
+    b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
 WIDE_CASES = [SIZES[10], SIZES[11],
               # cfg4' at its first iCEM iteration's batch: 20 020 rows = 4 004 per member = 126 two-tile workgroups per member, 630
               # logical workgroups on 256 CUs: the turn-based persistent form
