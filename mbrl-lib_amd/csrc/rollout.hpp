@@ -1461,6 +1461,11 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     constexpr int kG = 2;  // 16-byte pair loads in flight per thread and round (cfg2: 48 rows x 10 pairs = 480 items, one round)
     const int NVP = (md.obs_dim + 1) / 2 + 1;  // pairs per row
     const int NV = 2 * NVP;                    // granules per row
+    const unsigned nvp_magic = (unsigned)(0x100000000ull / (unsigned)NVP) + 1u;  // NVP >= 2
+    // rows wider than a few pairs (cfg4: 24 pairs per row, cfg4': 189) are collected in rounds of kGT pairs per thread, each round one
+    // round trip to the table (>= 1 us even when the rows are long there: the later turns of a step): 4 / 8 in flight instead of 2
+    // cut cfg4''s 12 rounds per turn to 3.  (Only the collect phase holds these registers; the straight form's cfg2 needs one round.)
+    constexpr int kGT = S::WIDE ? 8 : ((kLean && S::OUTC >= 4) ? 4 : kG);
     int xs[kG], xv[kG];
 #pragma unroll
     for (int q = 0; q < kG; ++q) {
@@ -2241,6 +2246,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             float av2[kPrefetch];
             fetch_actions_issue(t_next, av2);  // in flight while the rows arrive
             const unsigned long long tag = (unsigned long long)(ra.tag_base + (unsigned)t_next) << 32;  // published in step t_next - 1
+            // (Writing the normalised input columns straight from here, as the straight form does, measured SLOWER in this flow: cfg4'
+            // 10.5 vs 9.85 ms per rollout, cfg4 3.44 vs 3.37 -- with 12-24 pairs per thread the f64 work serialises behind every poll
+            // round, while the separate pass below spreads it over the workgroup.)
             if (t_next == ra.t_begin) {  // a later turn of the FIRST step: the rows start from s0 (nothing was handed over yet)
                 for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
                     const int s_ = i / md.obs_dim;
@@ -2251,17 +2259,19 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     sm.term[s_] = 0;
                 }
             } else
-            for (int base = 0; base < ROWS * NVP; base += kG * kThreads) {
-                const unsigned long long* src[kG];
-                u32x4g g[kG];
-                int gs[kG], gv[kG];
-                bool soft[kG];  // {running total, flag}: wanted at the NEXT reward phase only -- one look now, the rest there
+            for (int base = 0; base < ROWS * NVP; base += kGT * kThreads) {
+                const unsigned long long* src[kGT];
+                u32x4g g[kGT];
+                int gs[kGT], gv[kGT];
+                bool soft[kGT];  // {running total, flag}: wanted at the NEXT reward phase only -- one look now, the rest there
                 const unsigned want = (unsigned)(tag >> 32);
 #pragma unroll
-                for (int q = 0; q < kG; ++q) {
+                for (int q = 0; q < kGT; ++q) {
                     const int i = base + tid + q * kThreads;
-                    gs[q] = base == 0 ? xs[q] : (i < ROWS * NVP ? i / NVP : -1);
-                    gv[q] = base == 0 ? xv[q] : (i < ROWS * NVP ? i - (i / NVP) * NVP : 0);
+                    // (item -> (row slot, pair) by multiply-high with ceil(2^32 / NVP): exact for i < 2^32 / NVP, and i < 64 * NVP here)
+                    const int i_row = (int)__umulhi((unsigned)i, nvp_magic);
+                    gs[q] = (base == 0 && q < kG) ? xs[q < kG ? q : 0] : (i < ROWS * NVP ? i_row : -1);
+                    gv[q] = (base == 0 && q < kG) ? xv[q < kG ? q : 0] : (i < ROWS * NVP ? i - i_row * NVP : 0);
                     soft[q] = gv[q] == NVP - 1;
                     src[q] = nullptr;
                     g[q] = u32x4g{0u, want, 0u, want};  // rows of the padding: zero state, total, flag
@@ -2274,14 +2284,16 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 for (int spins = 0;; ++spins) {
                     // issue, issue, wait as straight-line asm (no branch between a load and its wait: the compiler does not know the
                     // destination registers are still in flight); items with nothing to fetch read the table's first pair and ignore it
-                    static_assert(kG == 2, "the wait below names the two destinations");
-                    u32x4g got[kG];
-                    pair_load_issue(got[0], src[0] ? src[0] : ra.exchange);
-                    pair_load_issue(got[1], src[1] ? src[1] : ra.exchange);
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1])::"memory");
+                    static_assert(kGT == 2 || kGT == 4 || kGT == 8, "the wait below names its destinations");
+                    u32x4g got[kGT];
+#pragma unroll
+                    for (int q = 0; q < kGT; ++q) pair_load_issue(got[q], src[q] ? src[q] : ra.exchange);
+                    if constexpr (kGT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1])::"memory");
+                    else if constexpr (kGT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3])::"memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]), "+v"(got[7])::"memory");
                     bool ready = true;
 #pragma unroll
-                    for (int q = 0; q < kG; ++q)
+                    for (int q = 0; q < kGT; ++q)
                         if (src[q]) {
                             g[q] = got[q];
                             if (got[q][1] == want && got[q][3] == want) src[q] = nullptr;
@@ -2299,12 +2311,13 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     __builtin_amdgcn_s_sleep(8);
                 }
 #pragma unroll
-                for (int q = 0; q < kG; ++q)
+                for (int q = 0; q < kGT; ++q)
                     if (gs[q] >= 0) {
                         if (!soft[q]) {
                             const int d = 2 * gv[q];
-                            sm.state[gs[q] * md.obs_dim + d] = __uint_as_float(g[q][0]);
-                            if (d + 1 < md.obs_dim) sm.state[gs[q] * md.obs_dim + d + 1] = __uint_as_float(g[q][2]);
+                            const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
+                            sm.state[gs[q] * md.obs_dim + d] = v0;
+                            if (d + 1 < md.obs_dim) sm.state[gs[q] * md.obs_dim + d + 1] = v1;
                         } else if (src[q]) {
                             sm.pend[gs[q]] = 1;  // not there yet: the reward phase fetches the pair
                         } else {
