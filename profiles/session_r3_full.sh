@@ -1,6 +1,10 @@
 #!/bin/bash
 # round 3 evidence session: profiles/session_full.sh r3 (smoke, the whole GPU test suite, default bench line, gloo2 bench, rocprofv3
 # collection) + the round's extra probes (k-loop probe, phase profile of the shape-specialised kernel, hand-over trace).
+# The probes need two variant builds of the library next to the shipped one (built HERE before the session, removed afterwards so
+# that only libhipets.so travels with the tree):
+#   python -c "import __graft_entry__ as g, os; [g.build_library(out=os.path.join(g.PKG,'hipets','libhipets_%s.so'%t), extra_flags=(f,), \
+#              objdir=os.path.join(g.PKG,'build_'+t), force=True) for t,f in (('prof','-DHIPETS_LEAN_PROF=1'),('trace','-DHIPETS_STEP_TRACE'))]"
 set -u
 export TMPDIR=/tmp
 bash profiles/session_full.sh r3
