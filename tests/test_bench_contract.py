@@ -78,16 +78,23 @@ def test_bench_constants_are_the_baseline_config():
 
 
 def test_pmc_summary_counts_the_kernel_this_repository_ships():
-    """profiles/r2_rollout_pmc.json: SQ_INSTS_MFMA per launch equals the count derived from the kernel's structure -- 2178
+    """profiles/r{2,3}_rollout_pmc.json: SQ_INSTS_MFMA per launch equals the count derived from the kernel's structure -- 2178
     v_mfma_f32_16x16x4_f32 per row-tile-step at cfg2 (input 13x6 + 3 x 13x50 + output 3x50 column-tile k-steps) x row tiles x
     horizon: 210 workgroups x 3 tiles in DEVICE mode (5 members x 42 groups), 220 x 3 in FAST mode (11 candidate groups x 20
     particles).  A counter file from another kernel or another workload would not reproduce these integers."""
     per_tile_step = 13 * 6 + 3 * 13 * 50 + 3 * 50
     assert per_tile_step == 2178
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_rollout_pmc.json")))
-    assert pmc["device"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (5 * 42 * 3) * 30
-    assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (11 * 20 * 3) * 30
+    for tag in ("r2", "r3"):  # round 3's fused output layer issues the same MFMAs (another pack of the same 3 column tiles)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_rollout_pmc.json")))
+        assert pmc["device"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (5 * 42 * 3) * 30, tag
+        assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (11 * 20 * 3) * 30, tag
+        for mode in ("device", "fast"):
+            d = pmc[mode]["derived"]
+            assert 0.4 < d["mfma_pipe_busy_frac_on_active_simds"] < 1.0
+            assert d["hbm_bytes_per_launch"] > 2.9e6  # at least the weight pack once
+    # round 3 against round 2: the matrix pipe is busier, the persistent form moves less
+    r2 = json.load(open(os.path.join(ROOT, "profiles", "r2_rollout_pmc.json")))
+    r3 = json.load(open(os.path.join(ROOT, "profiles", "r3_rollout_pmc.json")))
     for mode in ("device", "fast"):
-        d = pmc[mode]["derived"]
-        assert 0.4 < d["mfma_pipe_busy_frac_on_active_simds"] < 1.0
-        assert d["hbm_bytes_per_launch"] > 2.9e6  # at least the weight pack once
+        assert r3[mode]["derived"]["mfma_pipe_busy_frac_on_active_simds"] > r2[mode]["derived"]["mfma_pipe_busy_frac_on_active_simds"]
+    assert r3["device"]["derived"]["hbm_bytes_per_launch"] < r2["device"]["derived"]["hbm_bytes_per_launch"]
