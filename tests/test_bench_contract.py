@@ -98,3 +98,17 @@ def test_pmc_summary_counts_the_kernel_this_repository_ships():
     for mode in ("device", "fast"):
         assert r3[mode]["derived"]["mfma_pipe_busy_frac_on_active_simds"] > r2[mode]["derived"]["mfma_pipe_busy_frac_on_active_simds"]
     assert r3["device"]["derived"]["hbm_bytes_per_launch"] < r2["device"]["derived"]["hbm_bytes_per_launch"]
+
+
+def test_wide_instance_pmc_counts_the_cfg4p_kernel():
+    """profiles/r3_cfg4p_wide_fast_kernel.json (rocprofv3 --pmc of the cfg4' FAST rollout): SQ_INSTS_MFMA per launch is the count the
+    WIDE instance's structure gives -- per row-tile-step 13 x 99 (input: 393 columns = 98.25 k-steps of 4, the padding steps of
+    the last chunk skipped) + 3 x 13 x 50 (hidden) + 47 x 50 (the 752 output columns) k-steps, x 2 row tiles x 660 workgroups
+    (33 candidate groups x 20 particles) x horizon 40 -- and the kernel is the R = 2 instance of the (13, 47) shape."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r3_cfg4p_wide_fast_kernel.json")))
+    per_tile_step = 13 * 99 + 3 * 13 * 50 + 47 * 50
+    assert d["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (33 * 20 * 2) * 40
+    assert "rollout_kernel<2, hipets::KSpec<1, 13, 47," in d["kernel"]
+    assert d["algorithmic_flops_per_launch"] == 2 * (393 * 200 + 3 * 200 * 200 + 200 * 752) * 1036 * 20 * 40
+    assert d["frac_of_fp32_peak"] == pytest.approx(d["algorithmic_flops_per_launch"] / (d["avg_ns"] * 1e-9) / 157.3e12, rel=1e-9)
+    assert d["frac_of_fp32_peak"] > 0.40  # the round-2 verdict's target for this configuration
