@@ -182,7 +182,7 @@ def test_isa_scanner_sees_both_hazards_of_an_asm_mfma(tmp_path):
 
 
 def test_no_asm_mfma_of_the_shipped_library_sits_in_a_hazard():
-    """Every asm MFMA of the shipped kernels (44 k of them), checked in the final ISA at build time (scan_isa_hazards; the
+    """Every asm MFMA of the shipped kernels (52 k of them), checked in the final ISA at build time (scan_isa_hazards; the
     findings are recorded in the buildinfo file): no instruction touches an MFMA result that is still in flight, no VALU
     write lands on an MFMA operand without its wait states.  The compiler cannot see into the asm statements; round 3 found
     accumulator initialisations it had sunk to just in front of their first MFMA (wrong sums in the cfg4 instances)."""
