@@ -35,7 +35,10 @@ def kernel_ms(fn, n=20):
 
 for name, obs, act, pop, H, P, rew in [("cfg1_cartpole", 4, 1, 100, 15, 5, "cartpole"), ("cfg2_shard_of_8", 17, 6, 63, 30, 20, "halfcheetah"),
                                        ("cfg2_shard_of_4", 17, 6, 125, 30, 20, "halfcheetah"), ("cfg2_shard_of_2", 17, 6, 250, 30, 20, "halfcheetah")]:
-    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0, nontrivial_stats=False, reward=rew)
+    # (cartpole with its termination function, as the reference's config has it: the model then matches its shape-specialised instance;
+    # rounds 2 and 3 first timed it without, i.e. on the generic kernel)
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0, nontrivial_stats=False, reward=rew,
+                                 termination="cartpole" if rew == "cartpole" else "no_termination")
     eng.set_model(to_spec(om, obs, act))
     acts = (torch.rand(pop, H, act) * 2 - 1).to(dev)
     s0 = np.zeros(obs, np.float32)
