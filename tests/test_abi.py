@@ -198,3 +198,19 @@ def test_no_asm_mfma_of_the_shipped_library_sits_in_a_hazard():
     assert sorted(isa["units_scanned"]) == sorted(ge.UNITS)
     assert isa["asm_mfmas"] > 20000
     assert isa["hazards"] == [], isa["hazards"][:5]
+
+
+def test_kernel_resources_are_read_from_the_assembly_annotations(tmp_path):
+    """parse_kernel_resources on a hand-written snippet: registers / scratch / occupancy from the "; Kernel info:" block of a kernel,
+    spill counts from its metadata note; functions without a note (device functions) are not reported."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    p = tmp_path / "k.s"
+    p.write_text("helper:  ; @helper\n; NumVgprs: 12\n; ScratchSize: 0\n"
+                 "kern:    ; @kern\n\ts_endpgm\n; Kernel info:\n; NumVgprs: 254\n; NumAgprs: 68\n; ScratchSize: 16\n; Occupancy: 1\n"
+                 "amdhsa.kernels:\n  - .agpr_count: 68\n    .name:           kern\n    .sgpr_spill_count: 82\n    .vgpr_spill_count: 3\n")
+    res = ge.parse_kernel_resources(str(p))
+    assert res == {"kern": {"VGPRs": 254, "AGPRs": 68, "ScratchSize [bytes/lane]": 16, "Occupancy [waves/SIMD]": 1, "SGPRs Spill": 82, "VGPRs Spill": 3}}
