@@ -45,25 +45,51 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the sparsity headline is not used)
 
 
-def synthetic_spec(device, precision="f32"):
+def synthetic_spec(device, precision="f32", obs=OBS, act=ACT, ensemble=ENSEMBLE, elite=None, obs_process="none", no_delta_list=(),
+                   reward="halfcheetah", termination="no_termination", seed=0):
     """Random-init GaussianMLP ensemble with the reference initialiser (models/util.py:15-28: truncated
     normal std 1/(2 sqrt(in)), zero bias; logvar bounds -10 / 0.5), built on the product side (no oracle)."""
     import hipets
 
-    g = torch.Generator().manual_seed(0)
-    dims = [OBS + ACT] + [HID] * LAYERS + [2 * OBS]
+    g = torch.Generator().manual_seed(seed)
+    n_in = obs + (1 if obs_process == "cartpole_pets" else 0) + act
+    dims = [n_in] + [HID] * LAYERS + [2 * obs]
     ws, bs = [], []
     for i in range(len(dims) - 1):
         std = 1.0 / (2.0 * np.sqrt(dims[i]))
-        w = torch.empty(ENSEMBLE, dims[i], dims[i + 1])
+        w = torch.empty(ensemble, dims[i], dims[i + 1])
         torch.nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
         ws.append(w.to(device))
-        bs.append(torch.zeros(ENSEMBLE, 1, dims[i + 1], device=device))
+        bs.append(torch.zeros(ensemble, 1, dims[i + 1], device=device))
     return hipets.ModelSpec(
-        weights=ws, biases=bs, obs_dim=OBS, act_dim=ACT, min_logvar=-10 * torch.ones(1, OBS), max_logvar=0.5 * torch.ones(1, OBS),
-        activation="silu", propagation="random_model", norm_mean=torch.zeros(1, OBS + ACT, dtype=torch.float64),
-        norm_std=torch.ones(1, OBS + ACT, dtype=torch.float64), target_is_delta=True, learned_rewards=False,
-        reward="halfcheetah", termination="no_termination", precision=precision)
+        weights=ws, biases=bs, obs_dim=obs, act_dim=act, min_logvar=-10 * torch.ones(1, obs), max_logvar=0.5 * torch.ones(1, obs),
+        elite_models=elite, activation="silu", propagation="random_model", norm_mean=torch.zeros(1, n_in, dtype=torch.float64),
+        norm_std=torch.ones(1, n_in, dtype=torch.float64), target_is_delta=True, no_delta_list=list(no_delta_list), learned_rewards=False,
+        obs_process=obs_process, reward=reward, termination=termination, precision=precision)
+
+
+# Other workloads on the same line (never `value`): the configurations the reference ships as its defaults, and the remaining
+# BASELINE.json configs (parity-test cases: tests/test_gpu_plans_full_size.py pins each at this size).  Each: model kwargs of
+# synthetic_spec, optimizer kind + its stock parameters, P, H.
+STOCK_WORKLOADS = {
+    # conf/overrides/pets_halfcheetah.yaml:1-24 + conf/dynamics_model/gaussian_mlp_ensemble.yaml + conf/algorithm/pets.yaml:20 +
+    # env/pets_halfcheetah.py:91-113: obs 18 through HalfCheetahEnv.preprocess_fn, no_delta_list [0], 7 members / 5 elites
+    "pets_halfcheetah": dict(model=dict(obs=18, act=6, ensemble=7, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0]),
+                             optimizer="cem", pop=400, elite_ratio=0.16, alpha=0.12, P=20, H=30,
+                             source="conf/overrides/pets_halfcheetah.yaml (the reference's own default PETS workload)"),
+    # conf/overrides/pets_cartpole.yaml:1-21 + util/env.py:71-74
+    "pets_cartpole": dict(model=dict(obs=4, act=1, ensemble=7, elite=[1, 2, 4, 5, 6], reward="cartpole", termination="cartpole"),
+                          optimizer="cem", pop=350, elite_ratio=0.1, alpha=0.1, P=20, H=15, source="conf/overrides/pets_cartpole.yaml"),
+}
+OTHER_CONFIGS = {
+    "configs[0] cfg1 cartpole": dict(model=dict(obs=4, act=1, ensemble=5, reward="cartpole", termination="cartpole"), optimizer="cem", pop=100,
+                                     elite_ratio=0.1, alpha=0.1, P=5, H=15),
+    "configs[3] cfg4 iCEM humanoid_truncated_obs (obs 45)": dict(model=dict(obs=45, act=17, ensemble=7, elite=[0, 1, 2, 3, 4], termination="humanoid"),
+                                                                  optimizer="icem", pop=1000, P=20, H=40, s0_first=1.4),
+    "configs[3] cfg4' iCEM Humanoid-v4 (obs 376)": dict(model=dict(obs=376, act=17, ensemble=7, elite=[0, 1, 2, 3, 4], termination="humanoid"),
+                                                         optimizer="icem", pop=1000, P=20, H=40, s0_first=1.4),
+    "configs[4] cfg5 MPPI cheetah-run": dict(model=dict(obs=17, act=6, ensemble=5), optimizer="mppi", pop=2000, P=20, H=50),
+}
 
 
 def _usable_cores():
@@ -260,12 +286,10 @@ def main():
         eval_fn = hipets.make_eval_fn(spec_ if spec_ is not None else spec, PARTICLES, engine=engine, seed=0, mode=mode)
         opt = hipets.CEMOptimizer(ITERS, ELITE_RATIO, pop_total, lb, ub, ALPHA, device, return_mean_elites=True, seed=0)
         if sharded == "library":
-            engine.set_plan_mode(mode)
-            counter = {"n": 0}
-
-            def plan():
-                counter["n"] += 1
-                return engine.plan_cem_sharded(opt._params, x0, opt.lower_bound, opt.upper_bound, s0, PARTICLES, seed=0, plan_id=counter["n"])
+            # through the drop-in seam: CEMOptimizer.optimize sees the engine's communicator and runs hipets_plan_cem_sharded under
+            # hipets.dist.run_sharded (stream sync + the ranks' agreement on the outcome included: what agent.act() pays per plan)
+            objective = _BoundObjective(eval_fn, s0)
+            plan = lambda: opt.optimize(objective, x0=x0)  # noqa: E731
         elif sharded == "torch.distributed":
             objective = _BoundObjective(hdist.ShardedEvalFn(eval_fn), s0)  # generic path + one all-gather per iteration
             plan = lambda: opt.optimize(objective, x0=x0)  # noqa: E731
@@ -438,6 +462,84 @@ def main():
         extras["agent_act"] = {"workload": f"hipets.TrajectoryOptimizerAgent.act(obs) on configs[1] (mode='{args.mode}'), host observation in, host action out",
                                "ms_per_act": 1e3 * ea / na, "acts_per_s": na / ea, "ms_per_act_median": 1e3 * float(np.median(per_act)),
                                "ms_per_act_max": 1e3 * max(per_act), "acts": na}
+
+    def measure_workload(w, mode, n_plans, warm=2):
+        """One of STOCK_WORKLOADS / OTHER_CONFIGS through its optimizer class (fused plan: hipets_plan_{cem,mppi,icem}): plan time,
+        candidate-steps/s, and the rollout kernel's own launch durations (hipEvents on the dispatch packets of the timed plans)
+        priced with SURVEY.md 8(d)'s FLOP formula for THIS model."""
+        m = dict(w["model"])
+        spec_w = synthetic_spec(device, **m)
+        obs_w, act_w, H_w, P_w, kind = m["obs"], m["act"], w["H"], w["P"], w["optimizer"]
+        fn = hipets.make_eval_fn(spec_w, P_w, engine=engine, seed=0, mode=mode)
+        lb_w, ub_w = [[-1.0] * act_w] * H_w, [[1.0] * act_w] * H_w
+        s0_w = (np.random.default_rng(0).standard_normal(obs_w) * 0.1).astype(np.float32)
+        if "s0_first" in w:
+            s0_w[0] = w["s0_first"]  # a standing humanoid (termination_fns.py:88-95): rollouts that do not end at step 0
+        x0_w = torch.zeros(H_w, act_w, device=device)
+        if kind == "cem":
+            opt = hipets.CEMOptimizer(ITERS, w["elite_ratio"], w["pop"], lb_w, ub_w, w["alpha"], device, return_mean_elites=True, seed=0)
+            rows = [w["pop"]] * ITERS
+        elif kind == "mppi":  # conf/overrides/pets_mppi_halfcheetah.yaml:19-24
+            opt = hipets.MPPIOptimizer(ITERS, w["pop"], 0.9, 1.0, 0.9, lb_w, ub_w, device, seed=0)
+            rows = [w["pop"]] * ITERS
+        else:  # conf/overrides/pets_icem_cartpole.yaml:16-23; population sizes rounded up to multiples of the ensemble size
+            opt = hipets.ICEMOptimizer(ITERS, 0.1, w["pop"], 1.3, 2.0, lb_w, ub_w, 0.3, 0.1, device, return_mean_elites=True,
+                                       population_size_module=m["ensemble"], seed=0)
+            # every plan but the very first evaluates the kept elites too (and the extra `mu` row in its last iteration)
+            rows = [opt._iteration_size(i) + (1 if i == ITERS - 1 else int(opt.keep_elite_size)) for i in range(ITERS)]
+        objective = _BoundObjective(fn, s0_w)
+        plan = lambda: opt.optimize(objective, x0=x0_w)  # noqa: E731
+        for _ in range(warm):
+            plan()
+        engine.timing_enable(1)
+        engine.timing_read(reset=True)
+        plan()
+        torch.cuda.synchronize()
+        per_plan, _ = engine.timing_read(reset=True)
+        stride_w = 8 if per_plan > 4 * ITERS else 1
+        engine.timing_enable(stride_w)
+        engine.timing_read(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_plans):
+            sol = plan()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n_plans
+        n_l, k_ms = engine.timing_read(reset=True)
+        engine.timing_enable(False)
+        assert torch.isfinite(sol).all()
+        cs = sum(rows) * P_w * H_w
+        fl = spec_w.flops_per_candidate_step()
+        avg_ms = k_ms / max(n_l, 1)
+        kernel_ms_per_plan = avg_ms * per_plan
+        ach = cs * fl / (kernel_ms_per_plan * 1e-3) / 1e12
+        return {"ms_per_plan": 1e3 * el, "value": cs / el, "unit": "candidate-steps/s", "candidate_steps_per_plan": cs,
+                "candidates_per_iteration": rows, "plans_timed": n_plans,
+                "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                             "kernel": "hipets::rollout_kernel", "launches_per_plan": per_plan, "avg_launch_ms": avg_ms,
+                             "rollout_kernel_ms_per_plan": kernel_ms_per_plan, "flops_per_candidate_step": fl,
+                             "algorithmic_flops_per_plan": cs * fl,
+                             "launches_timed": "every launch of the timed plans" if stride_w == 1 else f"every {stride_w}-th launch of the timed plans"},
+                "plan_frac_of_fp32_peak_end_to_end": cs * fl / el / 1e12 / PEAK_FP32_TFLOPS}
+
+    if world == 1 and not args.no_extras:
+        # the configurations the reference ships as its defaults (what `python -m mbrl.examples.main algorithm=pets overrides=...`
+        # plans with): obs preprocessing, no_delta_list, 7 members / 5 elites, their own population sizes -- both randomness modes
+        stock = {}
+        for name, w in STOCK_WORKLOADS.items():
+            stock[name] = {"workload": f"{w['source']}: obs {w['model']['obs']} act {w['model']['act']}, {w['model']['ensemble']} members / "
+                                       f"{len(w['model']['elite'])} elites, CEM pop {w['pop']} x {w['P']} particles x H {w['H']}, elite ratio "
+                                       f"{w['elite_ratio']}, alpha {w['alpha']}, {ITERS} iterations"}
+            for m_ in (args.mode, other):
+                stock[name][m_] = measure_workload(w, m_, max(4, args.steps // 4))
+        extras["stock_defaults"] = stock
+        # the other BASELINE.json configs, headline mode (parity: tests/test_gpu_plans_full_size.py at exactly these sizes)
+        others = {}
+        for name, w in OTHER_CONFIGS.items():
+            others[name] = {"optimizer": w["optimizer"], args.mode: measure_workload(w, args.mode, 3 if w["pop"] >= 1000 else max(4, args.steps // 4))}
+        others["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"][other] = measure_workload(OTHER_CONFIGS["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"], other, 3)
+        extras["other_configs"] = others
+        engine.set_model(spec)
 
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON
     plans_done = args.steps * (world if sharded == "fallback" else 1)  # fallback: every rank planned on its own

@@ -25,7 +25,8 @@
  *   - HOST arrays are consumed before the call returns, so temporaries are fine: observations are copied into
  *     pinned staging buffers owned by the engine and uploaded asynchronously from there; model descriptors are
  *     uploaded inside hipets_set_model, which synchronises.
- *   - one engine per device; an engine is not thread-safe (the reference is single-threaded).
+ *   - one engine per device; an engine is not thread-safe (the reference is single-threaded).  Engines of DIFFERENT devices may
+ *     be driven from different host threads (the library's per-kernel residency table is locked).
  */
 #ifndef HIPETS_H
 #define HIPETS_H
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HIPETS_ABI_VERSION 3
+#define HIPETS_ABI_VERSION 4
 #define HIPETS_MAX_LAYERS 8
 
 typedef struct hipets_engine hipets_engine;
@@ -141,14 +142,23 @@ typedef struct {
                              /*   row -> member assignment, no batch % members rule                                      */
     int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
                              /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
-    int32_t generic_kernel;  /* 1 = never use a shape-specialised kernel instance (the library instantiates the rollout     */
-                             /*   kernel for the BASELINE shapes with layer shapes / reward / termination fns as compile-     */
-                             /*   time facts; same arithmetic -- tests compare the two bit for bit)                           */
+    int32_t generic_kernel;  /* 1 = only the fully generic kernel instance.  (The library also instantiates the rollout     */
+                             /*   kernel (a) for hidden widths of 193..208 -- the reference's default 200 -- with the hidden  */
+                             /*   layers' shape as a compile-time fact and everything else generic, and (b) for the BASELINE */
+                             /*   shapes with all layer shapes / reward / termination fns as compile-time facts; same        */
+                             /*   arithmetic -- tests compare them bit for bit.)  2 = (a) allowed, (b) not                   */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 int hipets_abi_version(void);
 const char* hipets_last_error(void);
+/* Class of this thread's last failure, for callers that must tell "the arguments were refused" (deterministic: every rank of
+ * a sharded job that passed the same arguments got the same answer) from "the machine failed" (may have hit one rank only):  */
+#define HIPETS_ERR_NONE 0
+#define HIPETS_ERR_INVALID_ARGUMENT 1 /* a value, shape or configuration the library rejects                                */
+#define HIPETS_ERR_RUNTIME 2          /* a HIP or RCCL call, an allocation or a kernel launch failed                         */
+#define HIPETS_ERR_TIMEOUT 3          /* a persistent DEVICE-mode rollout gave up waiting for another workgroup's rows       */
+int hipets_last_error_kind(void);
 int hipets_create(int device, hipets_engine** out);
 void hipets_destroy(hipets_engine* e);
 
@@ -201,7 +211,8 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
  * launch once per step).  What makes that safe:
  *   - residency is VERIFIED, not assumed: the first time a kernel instance is to run persistently at a larger grid than before,
  *     the library launches that very instance in a self-test mode in which every workgroup waits for all the others (one extra
- *     launch and ONE synchronisation of `stream`, once per instance and grid size); if they cannot meet, the runtime's smaller
+ *     launch and ONE synchronisation of `stream`, once per instance, LDS size (model / horizon) and grid size -- so the first plan
+ *     of a new shape is not capturable into a hipGraph, later ones are); if they cannot meet, the runtime's smaller
  *     occupancy answer is tried, and failing that the engine launches per step;
  *   - every poll is bounded (hipets_set_handover_timeout, default 0.2 s): if a producer never shows up (another process or
  *     stream took CUs after the self-test) the kernel raises a host-visible flag and drains in milliseconds.  The results of
@@ -242,6 +253,15 @@ int hipets_cem_sample(hipets_engine* e, const hipets_cem_params* p, const float*
 int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values, const float* population,
                      float* mu, float* dispersion, float* best_value, float* best_solution, int32_t* elite_idx,
                      void* stream);
+
+/* The same refit with the elites CHOSEN BY THE CALLER: elites DEVICE [elite_num] int32 candidate indices, best first (values must
+ * hold no index twice; out-of-range indices are the caller's error).  For seed-identical replays of the reference: the order
+ * torch.topk (:179) leaves among EQUAL values is an artefact of its partial sort, and 0 / 1 reward functions (cartpole,
+ * inverted pendulum: env/reward_fns.py:10-13, 27-30) tie dozens of candidates at the elite boundary -- the host runs the
+ * reference's own topk on the returned values and hands the indices in.  NaN -> -1e-10 still happens in place.           */
+int hipets_cem_refit_elites(hipets_engine* e, const hipets_cem_params* p, float* values, const float* population,
+                            const int32_t* elites, float* mu, float* dispersion, float* best_value, float* best_solution,
+                            void* stream);
 
 /* population[elite_idx] -> dst (the persistent ICEMOptimizer.elite, trajectory_opt.py:476): rows of src
  * [n_src, D] selected by index DEVICE int32 [rows].                                                          */
@@ -371,6 +391,19 @@ int hipets_comm_info(hipets_engine* e, int32_t* rank, int32_t* world_size);
  * a plan (hipets.dist.plan_cem_sharded does).  hipets_set_plan_trace records the gathered values like hipets_plan_cem's.   */
 int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
                             const float* s0, int32_t num_particles, uint64_t seed, uint64_t plan_id, float* out, void* stream);
+
+/* The same scheme for the other two optimizers ("MPPI: same all-gather of values (weights need global max and
+ * sum)"; "iCEM: kept elites are replicated state, so same scheme"): arguments as hipets_plan_mppi / hipets_plan_icem, identical
+ * on every rank; sampling (MPPI's smoothed noise; iCEM's coloured noise, kept / shifted elites, the +1 mu row) is replicated,
+ * every iteration's population -- iCEM's shrinks from iteration to iteration, the shards with it -- is rolled out shard-wise and
+ * its returns all-gathered, the importance-weighted mean (:297-311) / the elite refit (:474-485) then runs on identical data
+ * everywhere: bit-identical persistent state (`mean`, `elite`) on all ranks.  Same refusal / failure rules as above.       */
+int hipets_plan_mppi_sharded(hipets_engine* e, int32_t population_size, int32_t horizon, int32_t act_dim, int32_t num_iterations,
+                             double gamma, double beta, float* mean, const float* lower, const float* upper, const float* s0,
+                             int32_t num_particles, uint64_t seed, uint64_t plan_id, void* stream);
+int hipets_plan_icem_sharded(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
+                             float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t num_particles,
+                             uint64_t seed, uint64_t plan_id, float* out, void* stream);
 
 /* ---- PlaNet latent planner (mbrl/models/planet.py) ----------------------------------- */
 /* The tensors PlaNetModel.sample reads (planet.py:531-581), DEVICE f32 in nn.Linear layout: weights [out, in]

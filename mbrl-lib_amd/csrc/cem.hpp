@@ -19,6 +19,11 @@ struct CemDev {
     // per-row totals and this kernel reduces them, instead of a kernel launch of its own in between
     const float* totals = nullptr;
     int P = 0;
+    // refit only: when set, the caller has chosen the elites (DEVICE [n_env][K] candidate indices, best first) and the kernel's own
+    // selection is skipped.  For the reference-order parity mode of the optimizer classes (sampler='torch'): torch.topk's order
+    // among EQUAL values is whatever its partial sort leaves (trajectory_opt.py:179), and the 0 / 1 rewards of the cartpole family
+    // tie dozens of candidates at the elite boundary -- no closed-form tie rule reproduces that, the host's own topk does.
+    const int* elite_in = nullptr;
 };
 
 // Standard normal truncated to [-2, 2] by rejection: the stationary law of the reference's
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         best_solution += (size_t)env * p.D;
         if (elite_idx_out) elite_idx_out += (size_t)env * p.K;
     }
+    const int* const elite_in = p.elite_in ? p.elite_in + (size_t)blockIdx.x * p.K : nullptr;
     int n2 = 1;
     while (n2 < p.pop) n2 <<= 1;
     float* key = reinterpret_cast<float*>(smem);
@@ -122,7 +128,13 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     }
     __syncthreads();
     // order: "a before b" iff (key_a > key_b) or (equal and idx_a < idx_b)
-    if (p.pop <= kRankSortMax) {
+    if (elite_in) {  // the caller's elites, in the caller's order
+        const float top_key = key[elite_in[0]];
+        __syncthreads();
+        for (int k = tid; k < p.K; k += kRefitThreads) idx[k] = elite_in[k];
+        if (tid == 0) key[0] = top_key;  // key[] is only consulted at position 0 from here on
+        __syncthreads();
+    } else if (p.pop <= kRankSortMax) {
         // small populations (every PETS config): rank by counting -- element i sits at position #{j before i}.  One pass of
         // pop LDS broadcast reads per element and a single barrier instead of the ~log^2(n)/2 barrier stages of the
         // network below (45 for pop 500); only the first K positions (the elites) and position 0 (the best) are consumed.

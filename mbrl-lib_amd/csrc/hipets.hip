@@ -23,7 +23,9 @@ using namespace hipets;
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_err_kind = HIPETS_ERR_NONE;  // class of the last failure of this thread (hipets_last_error_kind)
 
+// an argument / configuration the library rejects: deterministic, the same on every rank that passes the same arguments
 int fail(const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -31,13 +33,26 @@ int fail(const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    g_err_kind = HIPETS_ERR_INVALID_ARGUMENT;
+    return 1;
+}
+
+// something the machine did (a HIP / RCCL call, an allocation, a launch, a hand-over time-out): may hit one rank only
+int fail_kind(const int kind, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    g_err_kind = kind;
     return 1;
 }
 
 #define HCHECK(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        if (_e != hipSuccess) return fail_kind(HIPETS_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
 struct DevBuf {
@@ -49,7 +64,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        if (e != hipSuccess) return fail_kind(HIPETS_ERR_RUNTIME, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         cap = bytes;
         return 0;
     }
@@ -148,7 +163,7 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
     if (err == hipErrorNotSupported && e->md.precision == HIPETS_PREC_BF16X3)
         return fail("precision bf16x3: no shape-specialised kernel instance for this model / call (SiLU, f64 normaliser, no obs "
                     "preprocessing, in-kernel sampling, one of the BASELINE layer shapes, R = %d); use precision f32", R);
-    if (err != hipSuccess) return fail("rollout kernel launch failed: %s", hipGetErrorString(err));
+    if (err != hipSuccess) return fail_kind(HIPETS_ERR_RUNTIME, "rollout kernel launch failed: %s", hipGetErrorString(err));
     return 0;
 }
 
@@ -163,8 +178,13 @@ size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
                               md.propagation == HIPETS_PROP_EXPECTATION, md.lv_rows);
 }
 
-// cost model for the row-tile count R of a workgroup: (sequential workgroup rounds per CU) x (MFMA units
-// the busiest wave issues per hidden layer).  See DESIGN.md "Choosing R".
+// Cost model for the row-tile count R of a workgroup (DESIGN.md "Choosing R"), in units of "one MFMA unit through a layer's k loop"
+// (~2.7 us per step at hid 200).  A workgroup's step costs a + units(R): `units` = MFMA units per k-chunk of its busiest wave
+// (hid 200: 4, 7, 10, 13 for R = 1..4), a ~ 1.8 = what a step spends outside the k loops (epilogues, tail, set-up, barriers).
+// A CU holds two workgroups of an R <= 2 instance at once (256 registers each) and their fixed parts hide behind each other's MFMAs:
+// a pair costs a + 2 units; R >= 3 instances own the CU (512 registers) and their workgroups run one after the other.  A (shape, R)
+// pair without a shape-specialised instance (launch.hpp lean_shape_exists) runs the hidden-static or the generic kernel: + 8 %.
+// Calibrated on MI355X (profiles/r4_stock_workloads.json: every R forced, three workloads, both modes).
 int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (waves w and w + 4 share SIMD w % 4)
     const int full = C / kWaves, rem = C % kWaves, nu = rem * R;
     int simd[4] = {0, 0, 0, 0};
@@ -175,6 +195,7 @@ int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (w
 int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon, bool wide = false) {
     if (forced > 0) return forced;
     const int C = e->md.hidC;
+    const double a = 1.77 * (double)C / 13.0;  // the fixed part scales with the layer width like the units do
     int best = 1;
     double best_cost = 1e300;
     for (int R = 1; R <= kMaxR; ++R) {
@@ -182,10 +203,12 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         if (wide && R > 2) break;  // WIDE instances exist for R = 1, 2 (rollout_inst.inc)
         const long long groups = (tiles_total_per_slice + R - 1) / R;
         const long long nwg = groups * slices;
-        const long long rounds = (nwg + e->num_cu - 1) / e->num_cu;
-        // measured on cfg2: a (round x unit) costs ~10 % more at R = 1, 2 (each B fragment feeds fewer MFMAs)
-        const double reuse_penalty = R == 1 ? 1.10 : (R == 2 ? 1.08 : 1.0);
-        const double cost = (double)rounds * wave_units(C, R) * reuse_penalty;
+        const long long n = (nwg + e->num_cu - 1) / e->num_cu;  // workgroups the busiest CU serves
+        const int co = (R <= 2 && !wide) ? 2 : 1;               // ... of which it holds this many at once
+        const double u = wave_units(C, R);
+        const long long full = n / co, rem = n % co;
+        double cost = (double)full * (a + co * u) + (rem ? a + (double)rem * u : 0.0);
+        if (!lean_shape_exists(e->md, R)) cost *= 1.08;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = R;
@@ -217,18 +240,27 @@ int stage_h2d(hipets_engine* e, void* dst, const void* src, size_t bytes, hipStr
 }
 
 // Every entry point that enqueues work on the engine's workspace calls this first: if `st` is not the stream of the previous
-// call, `st` waits (device side) for what that call enqueued.  Same stream: nothing to do.
+// call, `st` waits (device side) for what that call enqueued.  Same stream: nothing to do.  The event it waits for was recorded at
+// the END of the previous call, on that call's own stream, while the caller was still inside the library -- i.e. while the stream
+// was certainly alive (StreamScope below); nothing is ever recorded on a stream the caller may have destroyed since.
 int enter_stream(hipets_engine* e, hipStream_t st) {
-    if (e->last_stream_set && e->last_stream != st) {
-        if (!e->last_done) HCHECK(hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming));
-        // the previous stream may have been destroyed by its owner meanwhile: then there is nothing left to wait for
-        if (hipEventRecord(e->last_done, e->last_stream) == hipSuccess) HCHECK(hipStreamWaitEvent(st, e->last_done, 0));
-        else (void)hipGetLastError();
-    }
+    if (!e->last_done) HCHECK(hipEventCreateWithFlags(&e->last_done, hipEventDisableTiming));
+    if (e->last_stream_set && e->last_stream != st) HCHECK(hipStreamWaitEvent(st, e->last_done, 0));
     e->last_stream = st;
     e->last_stream_set = true;
     return 0;
 }
+// ... and holds one of these until it returns: marks the end of the call's work on its stream
+struct StreamScope {
+    hipets_engine* e;
+    hipStream_t st;
+    ~StreamScope() {
+        if (e && e->last_done) (void)hipEventRecord(e->last_done, st);
+    }
+};
+#define ENTER_STREAM(e, st)                \
+    if (enter_stream((e), (st))) return 1; \
+    StreamScope stream_scope_ { (e), (st) }
 
 // generate the member schedules of `iters` consecutive FAST rollouts (stream ids first_stream, +1, ...) of `pop` candidates
 // in ONE launch.  *sched = schedule of rollout 0 (rollout i: + i * H * nwg) or nullptr (expectation propagation).
@@ -285,13 +317,13 @@ int rccl_load() {
     const char* forced = std::getenv("HIPETS_RCCL_LIB");
     if (forced && forced[0]) {
         lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return fail("cannot load the RCCL library named by HIPETS_RCCL_LIB (%s): %s", forced, dlerror());
+        if (!lib) return fail_kind(HIPETS_ERR_RUNTIME, "cannot load the RCCL library named by HIPETS_RCCL_LIB (%s): %s", forced, dlerror());
     }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
         if (lib) break;
         lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!lib) return fail("cannot load librccl: %s", dlerror());
+    if (!lib) return fail_kind(HIPETS_ERR_RUNTIME, "cannot load librccl: %s", dlerror());
     g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclId, int)>(dlsym(lib, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
@@ -299,14 +331,14 @@ int rccl_load() {
     g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(lib, "ncclGetErrorString"));
     g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(lib, "ncclCommCount"));
     g_rccl.CommUserRank = reinterpret_cast<int (*)(void*, int*)>(dlsym(lib, "ncclCommUserRank"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) return fail("librccl lacks an expected symbol");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) return fail_kind(HIPETS_ERR_RUNTIME, "librccl lacks an expected symbol");
     g_rccl.lib = lib;
     return 0;
 }
 #define NCHECK(x)                                                                                        \
     do {                                                                                                 \
         const int r_ = (x);                                                                              \
-        if (r_ != 0) return fail("RCCL error %d (%s) at %s:%d", r_, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
+        if (r_ != 0) return fail_kind(HIPETS_ERR_RUNTIME, "RCCL error %d (%s) at %s:%d", r_, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?", __FILE__, __LINE__); \
     } while (0)
 
 // candidates of rank r when pop candidates are dealt to `world` ranks (first pop % world ranks hold one more)
@@ -379,6 +411,8 @@ int hipets_abi_version(void) { return HIPETS_ABI_VERSION; }
 
 const char* hipets_last_error(void) { return g_err.c_str(); }
 
+int hipets_last_error_kind(void) { return g_err_kind; }
+
 int hipets_create(int device, hipets_engine** out) {
     if (!out) return fail("null out pointer");
     *out = nullptr;
@@ -430,7 +464,7 @@ int hipets_set_model(hipets_engine* e, const hipets_model_desc* d, void* stream)
     if (!e || !d) return fail("null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     if (d->n_layers < 2 || d->n_layers > HIPETS_MAX_LAYERS) return fail("n_layers %d outside [2, %d]", d->n_layers, HIPETS_MAX_LAYERS);
     if (d->n_members < 1 || d->n_members > d->ensemble_size) return fail("n_members %d invalid for ensemble_size %d", d->n_members, d->ensemble_size);
     if (d->obs_dim < 1 || d->act_dim < 1 || d->in_dim < d->act_dim + 1 || d->hid < 1) return fail("bad dimensions");
@@ -625,7 +659,10 @@ extern "C" {
 
 int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
                    const hipets_rollout_opts* o, float* returns, void* stream) {
-    if (!s0) return fail("null argument");
+    if (!e || !s0) return fail("null argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    ENTER_STREAM(e, st);
     return rollout_impl(e, actions, s0, pop, H, P, o, returns, stream, nullptr);
 }
 
@@ -640,13 +677,12 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     if (e->error_flag && *e->error_flag) {  // raised by an EARLIER launch: its returns were garbage
         *e->error_flag = 0;
         e->persistent_ok = false;  // fall back to one launch per step from now on
-        return fail("a persistent DEVICE-mode rollout timed out waiting for rows of another workgroup (its workgroups were not all "
+        return fail_kind(HIPETS_ERR_TIMEOUT, "a persistent DEVICE-mode rollout timed out waiting for rows of another workgroup (its workgroups were not all "
                     "resident) and nobody asked (hipets_check_async_error after the results were read): the results of that earlier "
                     "call are invalid.  Persistent launches are now disabled for this engine.");
     }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // (the public entry point that led here holds the StreamScope)
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
     const ModelDev& md = e->md;
     const long long B = (long long)pop * P;
     if (B > 0x7FFFFFFF / std::max(md.obs_dim, md.out_dim)) return fail("batch too large");
@@ -810,7 +846,8 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         const long long tiles = (pop + kTile - 1) / kTile;
         ra.eps = o->fast_eps;
         ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
-        // (a caller-sized member schedule follows hipets_fast_geometry, which reports the general layout's geometry)
+        // (a caller-sized member schedule follows hipets_fast_geometry: the default call's geometry -- the WIDE instance's where one
+        // will run; rows_per_group = -1 asks for the general layout's, which is what calls with injected eps / traces run)
         const bool wide = wide_model(md) && lean_call(md, ra) && o->rows_per_group <= 2;
         if (!wide && wide_model(md) && o->member_schedule && o->rows_per_group == 0)
             return fail("this call runs the general kernel layout (injected eps / traces / generic_kernel) on a model whose default geometry is "
@@ -852,6 +889,79 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
 
 }  // namespace
 
+namespace {
+
+// First local failure of a sharded plan on this rank (message + class).  A rank on which something cannot be enqueued must NOT
+// leave the plan: its peers are, or will be, waiting in this and the remaining iterations' collectives.  It keeps contributing
+// (stale) shards to every ncclAllGather and reports its own error at the end; the peers' plans are then built on garbage, which is
+// why hipets.dist agrees on the outcome over all ranks (an all-reduce of the status) before anybody uses a plan.
+struct LocalErr {
+    std::string msg;
+    int kind = HIPETS_ERR_NONE;
+    bool ok() const { return kind == HIPETS_ERR_NONE; }
+    void note(const int rc) {  // rc of a call that has just set g_err / g_err_kind
+        if (rc && ok()) { msg = g_err; kind = g_err_kind == HIPETS_ERR_NONE ? HIPETS_ERR_RUNTIME : g_err_kind; }
+    }
+    int report() const {
+        if (ok()) return 0;
+        g_err = msg;
+        g_err_kind = kind;
+        return 1;
+    }
+};
+
+// Everything that can fail for ONE rank's shard size must fail on EVERY rank, before the first collective (a rank that returned
+// early would leave its peers blocked in ncclAllGather): the shards of `rows` candidates hold rows / world or one more, and
+// EXACT / DEVICE-mode rollouts of a GaussianMLP ensemble need shard rows % members == 0 (gaussian_mlp.py:195-200) for both sizes.
+int check_shards(const hipets_engine* e, const int rows, const int P) {
+    const int world = e->comm_world;
+    if (rows < world) return fail("population_size %d < world_size %d", rows, world);
+    if (e->plan_mode == HIPETS_MODE_DEVICE && !e->md.iid_members) {
+        const int base = rows / world, extra = rows % world;
+        for (int n : {base, extra ? base + 1 : base})
+            if (((long long)n * P) % e->md.M != 0)
+                return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. A shard of %d candidates x %d "
+                            "particles = %lld rows for %d models (population %d over %d ranks).", n, P, (long long)n * P, e->md.M, rows, world);
+    }
+    return 0;
+}
+
+// The objective of one iteration of a sharded plan: `population` holds ALL `rows` candidates (sampled identically on
+// every rank: counter-based RNG), this rank rolls out its shard shard_bounds(rows, world, rank) with all particles, ONE
+// ncclAllGather of the per-candidate returns (padded to ceil(rows / world) per rank), and e->values [rows] then holds every
+// candidate's return on every rank.  The caller has sized e->values / shard_values / gathered.  Returns non-zero only when the
+// collective itself failed (RCCL error: the plan is over for everybody); local failures go to *le and the collective still runs.
+int sharded_evaluate(hipets_engine* e, const float* population, const int rows, const int H, const int P, const hipets_rollout_opts* ro,
+                     const int* presched, void* stream, LocalErr* le) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int world = e->comm_world, rank = e->comm_rank;
+    int lo, hi;
+    shard_bounds(rows, world, rank, &lo, &hi);
+    const int width = (rows + world - 1) / world;
+    const size_t nd = (size_t)H * e->md.act_dim;
+    float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
+    if (le->ok()) le->note(rollout_impl(e, population + (size_t)lo * nd, nullptr, hi - lo, H, P, ro, shard_out, stream, presched));
+    if (world > 1) {  // every rank, every iteration, whatever happened locally
+        NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
+        if (le->ok()) {
+            hipLaunchKernelGGL(unpad_shards_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, e->gathered.as<float>(), e->values.as<float>(), rows,
+                               world, width);
+            const hipError_t err = hipGetLastError();
+            if (err != hipSuccess) le->note(fail_kind(HIPETS_ERR_RUNTIME, "unpad_shards_kernel launch failed: %s", hipGetErrorString(err)));
+        }
+    }
+    return 0;
+}
+
+int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta, int32_t n_env,
+                   float* mean, const float* lower, const float* upper, const float* s0, int32_t P, uint64_t seed, uint64_t plan_id,
+                   void* stream, bool sharded);
+int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env, const float* x0, const float* lower, const float* upper,
+                   float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed, uint64_t plan_id,
+                   float* out, void* stream, bool sharded);
+
+}  // namespace
+
 extern "C" {
 
 int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t B, const hipets_rollout_opts* o, float* next_obs,
@@ -861,7 +971,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
     if (B < 1) return fail("bad batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const ModelDev& md = e->md;
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
     if (!md.iid_members && B % md.M != 0 && !(o->mode == HIPETS_MODE_EXACT && o->rows_per_member > 0))  // gaussian_mlp.py:195-200
@@ -1016,6 +1126,7 @@ int hipets_check_async_error(hipets_engine* e, int32_t* timed_out) {
         *e->error_flag = 0;
         e->persistent_ok = false;  // per-step launches from now on (hipets_set_persistent(e, 1) switches back)
         *timed_out = 1;
+        g_err_kind = HIPETS_ERR_TIMEOUT;
         g_err = "a persistent DEVICE-mode rollout gave up waiting for rows of another workgroup (its workgroups were not all resident: "
                 "another process or stream held CUs); everything computed from that launch on is invalid -- re-run the call.  "
                 "Persistent launches are now disabled for this engine.";
@@ -1056,6 +1167,22 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
     while (n2 < c.pop) n2 <<= 1;
     hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, elite_idx);
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+int hipets_cem_refit_elites(hipets_engine* e, const hipets_cem_params* p, float* values, const float* population, const int32_t* elites,
+                            float* mu, float* dispersion, float* best_value, float* best_solution, void* stream) {
+    if (!e) return fail("null engine");
+    if (check_cem(p)) return 1;
+    if (!values || !population || !elites || !mu || !dispersion || !best_value || !best_solution) return fail("null argument");
+    HCHECK(hipSetDevice(e->device));
+    CemDev c = make_cem(p);
+    c.elite_in = elites;
+    int n2 = 1;
+    while (n2 < c.pop) n2 <<= 1;
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
+                       values, population, mu, dispersion, best_value, best_solution, (int*)nullptr);
     HCHECK(hipGetLastError());
     return 0;
 }
@@ -1139,7 +1266,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const CemDev c = make_cem(p, n_env);
     const size_t nd = (size_t)n_env * c.D, npop = (size_t)n_env * c.pop;
     if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure((size_t)n_env * 4 + 16) ||
@@ -1196,6 +1323,22 @@ int hipets_plan_mppi(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_
 int hipets_plan_mppi_batched(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta,
                              int32_t n_env, float* mean, const float* lower, const float* upper, const float* s0, int32_t P,
                              uint64_t seed, uint64_t plan_id, void* stream) {
+    return plan_mppi_impl(e, pop, H, A, num_iterations, gamma, beta, n_env, mean, lower, upper, s0, P, seed, plan_id, stream, false);
+}
+
+int hipets_plan_mppi_sharded(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta,
+                             float* mean, const float* lower, const float* upper, const float* s0, int32_t P, uint64_t seed,
+                             uint64_t plan_id, void* stream) {
+    if (e && !e->comm) return fail("no communicator (call hipets_comm_init)");
+    return plan_mppi_impl(e, pop, H, A, num_iterations, gamma, beta, 1, mean, lower, upper, s0, P, seed, plan_id, stream, true);
+}
+
+}  // extern "C"
+
+namespace {
+int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t num_iterations, double gamma, double beta, int32_t n_env,
+                   float* mean, const float* lower, const float* upper, const float* s0, int32_t P, uint64_t seed, uint64_t plan_id,
+                   void* stream, const bool sharded) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!mean || !lower || !upper || !s0) return fail("null argument");
     if (pop < 1 || pop > 12000) return fail("population_size %d outside [1, 12000]", pop);
@@ -1203,42 +1346,69 @@ int hipets_plan_mppi_batched(hipets_engine* e, int32_t pop, int32_t H, int32_t A
     if (A != e->md.act_dim) return fail("act_dim %d != model act_dim %d", A, e->md.act_dim);
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
+    if (sharded && check_shards(e, pop, P)) return 1;  // identical on every rank, before any collective
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const size_t nd = (size_t)H * A, npop = (size_t)n_env * pop;
+    const int world = sharded ? e->comm_world : 1, rank = sharded ? e->comm_rank : 0;
+    const int width = (pop + world - 1) / world;
     if (e->mu.ensure(n_env * nd * 4) || e->past_action.ensure((size_t)n_env * A * 4) || e->population.ensure(npop * nd * 4) ||
         e->values.ensure(npop * 4))
         return 1;
-    HCHECK(hipMemcpyAsync(e->mu.p, mean, n_env * nd * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((n_env * nd + 255) / 256)), dim3(256), 0, st, n_env, H, A, e->mu.as<float>(), mean,
-                       e->past_action.as<float>());
-    HCHECK(hipGetLastError());
+    if (sharded && (e->shard_values.ensure((size_t)width * 4) || e->gathered.ensure((size_t)world * width * 4))) return 1;
+    LocalErr le;  // (only a sharded plan carries on after a local failure: its peers wait in the collectives)
     hipets_rollout_opts ro{};
     ro.mode = e->plan_mode;
-    ro.seed = seed;
+    ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_mppi)
     ro.n_env = n_env;
     const int* sched = nullptr;
     size_t sched_stride = 0;
-    if (plan_prologue(e, s0, n_env, (int)npop, P, H, num_iterations, seed, plan_id * (uint64_t)num_iterations, st, &sched, &sched_stride)) return 1;
+    int lo = 0, hi = pop;
+    if (sharded) shard_bounds(pop, world, rank, &lo, &hi);
+    auto prologue = [&]() -> int {
+        if (sharded) HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
+        HCHECK(hipMemcpyAsync(e->mu.p, mean, n_env * nd * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((n_env * nd + 255) / 256)), dim3(256), 0, st, n_env, H, A, e->mu.as<float>(), mean,
+                           e->past_action.as<float>());
+        HCHECK(hipGetLastError());
+        return plan_prologue(e, s0, n_env, sharded ? hi - lo : (int)npop, P, H, num_iterations, ro.seed, plan_id * (uint64_t)num_iterations, st, &sched,
+                             &sched_stride);
+    };
+    le.note(prologue());
+    if (!sharded && !le.ok()) return le.report();
     for (int k = 0; k < num_iterations; ++k) {
         const uint64_t sid = plan_id * (uint64_t)num_iterations + (uint64_t)k;
-        const long long n = (long long)npop * A;
-        hipLaunchKernelGGL(mppi_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_env, pop, H, A, (float)beta, mean,
-                           e->past_action.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
-                           e->population.as<float>());
-        HCHECK(hipGetLastError());
+        auto sample = [&]() -> int {
+            const long long n = (long long)npop * A;
+            hipLaunchKernelGGL(mppi_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_env, pop, H, A, (float)beta, mean,
+                               e->past_action.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
+                               e->population.as<float>());  // sharded: identical on every rank (same seed, same counters)
+            HCHECK(hipGetLastError());
+            return 0;
+        };
+        auto update = [&]() -> int {
+            hipLaunchKernelGGL(mppi_update_kernel, dim3(n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
+                               e->values.as<float>(), e->population.as<float>(), mean);
+            HCHECK(hipGetLastError());
+            return trace_iter(e, k, (int)npop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st, n_env);
+        };
+        if (le.ok()) le.note(sample());
         ro.stream_id = sid;
-        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, H, P, &ro, e->values.as<float>(), stream,
-                         sched ? sched + (size_t)k * sched_stride : nullptr))
-            return 1;
-        hipLaunchKernelGGL(mppi_update_kernel, dim3(n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
-                           e->values.as<float>(), e->population.as<float>(), mean);
-        HCHECK(hipGetLastError());
-        if (trace_iter(e, k, (int)npop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st, n_env)) return 1;
+        const int* ps = sched ? sched + (size_t)k * sched_stride : nullptr;
+        if (sharded) {
+            if (sharded_evaluate(e, e->population.as<float>(), pop, H, P, &ro, ps, stream, &le)) return 1;
+        } else if (le.ok()) {
+            le.note(rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, H, P, &ro, e->values.as<float>(), stream, ps));
+        }
+        if (le.ok()) le.note(update());
+        if (!sharded && !le.ok()) break;
     }
-    return 0;
+    return le.report();
 }
+}  // namespace
+
+extern "C" {
 
 int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
                      float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed,
@@ -1249,6 +1419,22 @@ int hipets_plan_icem(hipets_engine* e, const hipets_icem_params* p, const float*
 int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int32_t n_env, const float* x0, const float* lower,
                              const float* upper, float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P,
                              uint64_t seed, uint64_t plan_id, float* out, void* stream) {
+    return plan_icem_impl(e, p, n_env, x0, lower, upper, elite, has_elite, keep_idx, s0, P, seed, plan_id, out, stream, false);
+}
+
+int hipets_plan_icem_sharded(hipets_engine* e, const hipets_icem_params* p, const float* x0, const float* lower, const float* upper,
+                             float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed,
+                             uint64_t plan_id, float* out, void* stream) {
+    if (e && !e->comm) return fail("no communicator (call hipets_comm_init)");
+    return plan_icem_impl(e, p, 1, x0, lower, upper, elite, has_elite, keep_idx, s0, P, seed, plan_id, out, stream, true);
+}
+
+}  // extern "C"
+
+namespace {
+int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env, const float* x0, const float* lower, const float* upper,
+                   float* elite, int32_t has_elite, const int32_t* keep_idx, const float* s0, int32_t P, uint64_t seed, uint64_t plan_id,
+                   float* out, void* stream, const bool sharded) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!p || !x0 || !lower || !upper || !elite || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
@@ -1258,25 +1444,33 @@ int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int3
     if (p->population_size < 1 || iters < 0 || !(p->population_decay_factor > 0.0)) return fail("bad iCEM parameters");
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
     if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
-    // population sizes (:419-431) are known up front: size the workspace for the largest
-    std::vector<int> sizes(iters);
+    // population sizes (:419-431) and the rows every iteration evaluates are known up front: size the workspace for the largest, and
+    // (sharded) refuse on EVERY rank, before the first collective, what one rank's shard of some iteration could not take
+    std::vector<int> sizes(iters), rows_of(iters);
     int max_rows = 1;
-    for (int i = 0; i < iters; ++i) {
+    for (int i = 0, he = has_elite; i < iters; ++i, he = 1) {
         int n = (int)std::ceil(std::fmax((double)p->population_size * std::pow(p->population_decay_factor, -(double)i), 2.0 * K));
         const int m = p->population_size_module;
         if (m > 0 && n % m) n += m - n % m;
         sizes[i] = n;
         if (n + keep > kMaxPop) return fail("iCEM iteration %d evaluates %d candidates (max %d)", i, n + keep, kMaxPop);
+        rows_of[i] = n + (he ? ((i == iters - 1 && i != 0) ? 1 : keep) : 0);
+        if (K > rows_of[i]) return fail("elite_num %d invalid", K);
         max_rows = std::max(max_rows, n + keep);
+        if (sharded && check_shards(e, rows_of[i], P)) return 1;
     }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    ENTER_STREAM(e, st);
     const size_t nd = (size_t)H * A, ne = (size_t)n_env;
+    const int world = sharded ? e->comm_world : 1, rank = sharded ? e->comm_rank : 0;
+    const int max_width = (max_rows + world - 1) / world;
     if (e->mu.ensure(ne * nd * 4) || e->disp.ensure(ne * nd * 4) || e->best_solution.ensure(ne * nd * 4) || e->best_value.ensure(ne * 4 + 16) ||
         e->population.ensure(ne * max_rows * nd * 4) || e->values.ensure(ne * max_rows * 4) ||
-        e->kept.ensure(ne * std::max(keep, 1) * nd * 4) || e->elite_idx.ensure(ne * K * 4) || e->keep_idx.ensure(ne * std::max(keep, 1) * 4))
+        e->kept.ensure(ne * std::max(keep, 1) * nd * 4) || e->elite_idx.ensure(ne * K * 4) || e->keep_idx.ensure(ne * std::max(keep, 1) * 4) ||
+        e->s0.ensure(ne * e->md.obs_dim * 4))
         return 1;
+    if (sharded && (e->shard_values.ensure((size_t)max_width * 4) || e->gathered.ensure((size_t)world * max_width * 4))) return 1;
     hipets_cem_params cp{};
     cp.population_size = std::max(K, 1);
     cp.horizon = H;
@@ -1287,85 +1481,102 @@ int hipets_plan_icem_batched(hipets_engine* e, const hipets_icem_params* p, int3
     cp.return_mean_elites = p->return_mean_elites;
     cp.clipped_normal = 0;  // initial variance ((ub - lb)^2) / 16 (:373) and variance (not std) refit
     cp.unbiased_var = 0;    // :479
-    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((ne * nd + 255) / 256)), dim3(256), 0, st, make_cem(&cp, n_env), x0, lower, upper,
-                       e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>());
-    HCHECK(hipGetLastError());
-    HCHECK(hipMemsetAsync(e->best_solution.p, 0, ne * nd * 4, st));
+    LocalErr le;  // (only a sharded plan carries on after a local failure: its peers wait in the collectives)
     hipets_rollout_opts ro{};
     ro.mode = e->plan_mode;
-    ro.seed = seed;
+    ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_icem)
     ro.n_env = n_env;
-    if (e->s0.ensure(ne * e->md.obs_dim * 4)) return 1;  // the observations are the same for every iteration: stage them once
-    if (stage_h2d(e, e->s0.p, s0, ne * e->md.obs_dim * 4, st)) return 1;
     float* popbuf = e->population.as<float>();  // [n_env][rows][H][A], rows = this iteration's candidates per environment
-    for (int i = 0; i < iters; ++i) {
-        const int n = sizes[i];
-        const uint64_t sid = (plan_id * (uint64_t)iters + (uint64_t)i) * 4;
-        int extra = 0;
-        if (has_elite) extra = (i == iters - 1 && i != 0) ? 1 : keep;
-        const int rows = n + extra;
-        const int total = n_env * n * A;
-        hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, st, n_env, rows, n, H, A, (float)p->colored_noise_exponent,
-                           e->mu.as<float>(), e->disp.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed,
-                           (unsigned long long)sid, popbuf);
+    auto prologue = [&]() -> int {
+        if (sharded) HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)max_width * 4, st));  // padding slot of the shorter shards
+        hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((ne * nd + 255) / 256)), dim3(256), 0, st, make_cem(&cp, n_env), x0, lower, upper,
+                           e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>());
         HCHECK(hipGetLastError());
-        if (extra) {
+        HCHECK(hipMemsetAsync(e->best_solution.p, 0, ne * nd * 4, st));
+        return stage_h2d(e, e->s0.p, s0, ne * e->md.obs_dim * 4, st);  // the observations are the same for every iteration: staged once
+    };
+    le.note(prologue());
+    if (!sharded && !le.ok()) return le.report();
+    for (int i = 0; i < iters; ++i) {
+        const int n = sizes[i], rows = rows_of[i], extra = rows - n;
+        const uint64_t sid = (plan_id * (uint64_t)iters + (uint64_t)i) * 4;
+        auto sample = [&]() -> int {  // identical on every rank of a sharded plan: same seed, same counters
+            const int total = n_env * n * A;
+            hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, st, n_env, rows, n, H, A, (float)p->colored_noise_exponent,
+                               e->mu.as<float>(), e->disp.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed,
+                               (unsigned long long)sid, popbuf);
+            HCHECK(hipGetLastError());
+            if (!extra) return 0;
             float* tail = popbuf + (size_t)n * nd;  // environment 0's extra rows; the others follow rows * nd floats apart
             if (i == iters - 1 && i != 0) {  // :463-464
                 hipLaunchKernelGGL(icem_append_mu_kernel, dim3((unsigned)((ne * nd + 255) / 256)), dim3(256), 0, st, n_env, rows, n, (int)nd,
                                    e->mu.as<float>(), popbuf);
                 HCHECK(hipGetLastError());
-            } else {
-                const int32_t* kidx = keep_idx ? keep_idx + (size_t)i * n_env * keep : e->keep_idx.as<int32_t>();
-                if (!keep_idx) {
-                    hipLaunchKernelGGL(icem_keep_select_kernel, dim3(n_env), dim3(256), (size_t)K * 8, st, K, keep, (unsigned long long)seed,
-                                       (unsigned long long)(sid + 2), e->keep_idx.as<int32_t>());
-                    HCHECK(hipGetLastError());
-                }
-                const long long ng = (long long)keep * nd;
-                if (i == 0) {  // :450-462: kept elites shifted one step with a fresh tail action
-                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
-                                       e->kept.as<float>(), (long long)K * nd, (long long)keep * nd);
-                    HCHECK(hipGetLastError());
-                    hipLaunchKernelGGL(icem_shift_kernel, dim3((unsigned)((ne * ng + 255) / 256)), dim3(256), 0, st, n_env, rows, keep, H, A,
-                                       e->kept.as<float>(), e->mu.as<float>(), e->disp.as<float>(), (const float*)nullptr,
-                                       (unsigned long long)seed, (unsigned long long)(sid + 1), tail);
-                    HCHECK(hipGetLastError());
-                } else {  // :465-466
-                    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
-                                       tail, (long long)K * nd, (long long)rows * nd);
-                    HCHECK(hipGetLastError());
-                }
+                return 0;
             }
-        }
+            const int32_t* kidx = keep_idx ? keep_idx + (size_t)i * n_env * keep : e->keep_idx.as<int32_t>();
+            if (!keep_idx) {
+                hipLaunchKernelGGL(icem_keep_select_kernel, dim3(n_env), dim3(256), (size_t)K * 8, st, K, keep, (unsigned long long)seed,
+                                   (unsigned long long)(sid + 2), e->keep_idx.as<int32_t>());
+                HCHECK(hipGetLastError());
+            }
+            const long long ng = (long long)keep * nd;
+            if (i == 0) {  // :450-462: kept elites shifted one step with a fresh tail action
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
+                                   e->kept.as<float>(), (long long)K * nd, (long long)keep * nd);
+                HCHECK(hipGetLastError());
+                hipLaunchKernelGGL(icem_shift_kernel, dim3((unsigned)((ne * ng + 255) / 256)), dim3(256), 0, st, n_env, rows, keep, H, A,
+                                   e->kept.as<float>(), e->mu.as<float>(), e->disp.as<float>(), (const float*)nullptr,
+                                   (unsigned long long)seed, (unsigned long long)(sid + 1), tail);
+                HCHECK(hipGetLastError());
+            } else {  // :465-466
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 255) / 256), n_env), dim3(256), 0, st, keep, (int)nd, elite, kidx,
+                                   tail, (long long)K * nd, (long long)rows * nd);
+                HCHECK(hipGetLastError());
+            }
+            return 0;
+        };
+        auto refit = [&]() -> int {
+            cp.population_size = rows;
+            if (check_cem(&cp)) return 1;
+            int n2 = 1;
+            while (n2 < rows) n2 <<= 1;
+            hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
+                               e->values.as<float>(), popbuf, e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                               e->best_solution.as<float>(), e->elite_idx.as<int>());
+            HCHECK(hipGetLastError());
+            const long long nk = (long long)K * nd;  // self.elite = population[elite_idx] (:476), per environment
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nk + 255) / 256), n_env), dim3(256), 0, st, K, (int)nd, popbuf, e->elite_idx.as<int32_t>(),
+                               elite, (long long)rows * nd, (long long)K * nd);
+            HCHECK(hipGetLastError());
+            if (trace_iter(e, i, n_env * rows, nd, popbuf, e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st, n_env)) return 1;
+            if (e->has_trace && e->trace.elite_idx)
+                HCHECK(hipMemcpyAsync(e->trace.elite_idx + (size_t)i * n_env * K, e->elite_idx.p, ne * K * 4, hipMemcpyDeviceToDevice, st));
+            return 0;
+        };
+        if (le.ok()) le.note(sample());
         ro.stream_id = sid + 3;
-        if (rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream, nullptr)) return 1;  // s0 staged above
-        cp.population_size = rows;
-        if (check_cem(&cp)) return 1;
-        int n2 = 1;
-        while (n2 < rows) n2 <<= 1;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
-                           e->values.as<float>(), popbuf, e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
-                           e->best_solution.as<float>(), e->elite_idx.as<int>());
-        HCHECK(hipGetLastError());
-        const long long nk = (long long)K * nd;  // self.elite = population[elite_idx] (:476), per environment
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nk + 255) / 256), n_env), dim3(256), 0, st, K, (int)nd, popbuf, e->elite_idx.as<int32_t>(),
-                           elite, (long long)rows * nd, (long long)K * nd);
-        HCHECK(hipGetLastError());
-        has_elite = 1;
-        if (trace_iter(e, i, n_env * rows, nd, popbuf, e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st, n_env)) return 1;
-        if (e->has_trace && e->trace.elite_idx)
-            HCHECK(hipMemcpyAsync(e->trace.elite_idx + (size_t)i * n_env * K, e->elite_idx.p, ne * K * 4, hipMemcpyDeviceToDevice, st));
+        if (sharded) {
+            if (sharded_evaluate(e, popbuf, rows, H, P, &ro, nullptr, stream, &le)) return 1;
+        } else if (le.ok()) {
+            le.note(rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream, nullptr));  // s0 staged above
+        }
+        if (le.ok()) le.note(refit());
+        if (!sharded && !le.ok()) break;
     }
+    if (!le.ok()) return le.report();
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, ne * nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
+}  // namespace
+
+extern "C" {
 
 int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void* stream) {
     if (!e || !d) return fail("null argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     if (d->latent_size < 1 || d->action_size < 1 || d->belief_size < 1 || d->hidden_size < 1) return fail("bad PlaNet dimensions");
     const void* ptrs[] = {d->w_embed, d->b_embed, d->w_ih, d->b_ih, d->w_hh, d->b_hh, d->w_prior1, d->b_prior1,
                           d->w_prior2, d->b_prior2, d->w_rew1, d->b_rew1, d->w_rew2, d->b_rew2, d->w_rew3, d->b_rew3};
@@ -1447,7 +1658,7 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const long long B = (long long)pop * P;
     if (B > 0x7FFFFFFF / std::max(e->pd.belief, 16)) return fail("batch too large");
     if (e->totals.ensure((size_t)B * 4)) return 1;
@@ -1481,7 +1692,7 @@ int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const f
     if (p->act_dim != e->pd.action) return fail("act_dim %d != model action_size %d", p->act_dim, e->pd.action);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const CemDev c = make_cem(p, 1);
     const size_t nd = (size_t)c.D;
     if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
@@ -1569,22 +1780,11 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     if (check_cem(p)) return 1;
     if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
+    if (check_shards(e, p->population_size, P)) return 1;  // identical on every rank, before any collective
     const int world = e->comm_world, rank = e->comm_rank;
-    if (p->population_size < world) return fail("population_size %d < world_size %d", p->population_size, world);
-    // Everything that can fail for ONE rank's shard size must fail on EVERY rank, before the first collective (a rank that
-    // returned early would leave its peers blocked in ncclAllGather): the shards hold pop / world or one more candidates, and
-    // DEVICE-mode rollouts of a GaussianMLP ensemble need rows % members == 0 (gaussian_mlp.py:195-200) for both sizes.
-    if (e->plan_mode == HIPETS_MODE_DEVICE && !e->md.iid_members) {
-        const int base = p->population_size / world, extra = p->population_size % world;
-        for (int n : {base, extra ? base + 1 : base})
-            if (((long long)n * P) % e->md.M != 0)
-                return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. A shard of %d candidates x %d "
-                            "particles = %lld rows for %d models (population %d over %d ranks).", n, P, (long long)n * P, e->md.M,
-                            p->population_size, world);
-    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
-    if (enter_stream(e, st)) return 1;
+    ENTER_STREAM(e, st);
     const CemDev c = make_cem(p, 1);
     int lo, hi;
     shard_bounds(c.pop, world, rank, &lo, &hi);
@@ -1594,11 +1794,7 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
         e->population.ensure((size_t)c.pop * nd * 4) || e->values.ensure((size_t)c.pop * 4) || e->shard_values.ensure((size_t)width * 4) ||
         e->gathered.ensure((size_t)world * width * 4))
         return 1;
-    hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
-                       e->disp.as<float>(), e->best_value.as<float>());
-    HCHECK(hipGetLastError());
-    HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
-    HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
+    LocalErr le;
     hipets_rollout_opts ro{};
     ro.mode = e->plan_mode;
     ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_cem)
@@ -1606,48 +1802,39 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     while (n2 < c.pop) n2 <<= 1;
     const int* sched = nullptr;
     size_t sched_stride = 0;
-    if (plan_prologue(e, s0, 1, local, P, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st, &sched, &sched_stride))
-        return 1;
-    // A rank on which something cannot be enqueued (an allocation, a launch) must NOT leave the loop: its peers are, or will be,
-    // waiting in this and the remaining iterations' collectives.  It keeps contributing (stale) shards to every ncclAllGather and
-    // reports its own error at the end; the peers' plans are then built on garbage, which is why hipets.dist.plan_cem_sharded
-    // agrees on the outcome over all ranks (an all-reduce of the status) before anybody uses a plan.
-    std::string local_err;
-    auto enqueue_local = [&](const int i, const uint64_t sid, float* shard_out) -> int {
-        const long long n = (long long)c.pop * c.D;
-        hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
-                           lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
-                           e->population.as<float>());  // identical on every rank: same seed, same counters
+    auto prologue = [&]() -> int {
+        hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
+                           e->disp.as<float>(), e->best_value.as<float>());
         HCHECK(hipGetLastError());
-        ro.stream_id = sid;
-        return rollout_impl(e, e->population.as<float>() + (size_t)lo * nd, nullptr, local, c.H, P, &ro, shard_out, stream,
-                            sched ? sched + (size_t)i * sched_stride : nullptr);
+        HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
+        HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
+        return plan_prologue(e, s0, 1, local, P, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st, &sched, &sched_stride);
     };
-    auto refit_local = [&](const int i) -> int {
-        if (world > 1) {
-            hipLaunchKernelGGL(unpad_shards_kernel, dim3((c.pop + 255) / 256), dim3(256), 0, st, e->gathered.as<float>(), e->values.as<float>(),
-                               c.pop, world, width);
-            HCHECK(hipGetLastError());
-        }
-        int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
-                           e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
-                           e->best_solution.as<float>(), eidx);
-        HCHECK(hipGetLastError());
-        return trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st);
-    };
+    le.note(prologue());
     for (int i = 0; i < p->num_iterations; ++i) {
         const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
-        float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
-        if (local_err.empty() && enqueue_local(i, sid, shard_out)) local_err = g_err;
-        if (world > 1)  // every rank, every iteration, whatever happened locally
-            NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
-        if (local_err.empty() && refit_local(i)) local_err = g_err;
+        auto sample = [&]() -> int {
+            const long long n = (long long)c.pop * c.D;
+            hipLaunchKernelGGL(cem_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, e->mu.as<float>(), e->disp.as<float>(),
+                               lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
+                               e->population.as<float>());  // identical on every rank: same seed, same counters
+            HCHECK(hipGetLastError());
+            return 0;
+        };
+        auto refit = [&]() -> int {
+            int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
+            hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+                               e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
+                               e->best_solution.as<float>(), eidx);
+            HCHECK(hipGetLastError());
+            return trace_iter(e, i, c.pop, nd, e->population.as<float>(), e->values.as<float>(), e->mu.as<float>(), e->disp.as<float>(), st);
+        };
+        if (le.ok()) le.note(sample());
+        ro.stream_id = sid;
+        if (sharded_evaluate(e, e->population.as<float>(), c.pop, c.H, P, &ro, sched ? sched + (size_t)i * sched_stride : nullptr, stream, &le)) return 1;
+        if (le.ok()) le.note(refit());
     }
-    if (!local_err.empty()) {
-        g_err = local_err;
-        return 1;
-    }
+    if (!le.ok()) return le.report();
     HCHECK(hipMemcpyAsync(out, p->return_mean_elites ? e->mu.p : e->best_solution.p, nd * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }

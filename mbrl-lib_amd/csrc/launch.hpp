@@ -20,9 +20,63 @@ hipError_t launch_rollout_r4(int grid, unsigned lds, int lds_max, const ModelDev
 // R = 1 and 2 (rollout_inst.inc); the host sizes the LDS and chooses R for that layout exactly when the launcher will pick it.
 #define HIPETS_WIDE_SHAPES(X) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID)
 
-// does the call use nothing a lean instance compiled out? (KSpec in rollout.hpp lists what that is)
+// Hidden widths with a KSpec::HID_STATIC instance (hidden layers shape-specialised, everything else generic): X(hidden column tiles).
+// 13 tiles = hidden widths 193..208: the reference's default of 200 (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8).
+#define HIPETS_HID_STATIC_SHAPES(X) X(13)
+
+// may this model / call run the hidden-static instance for `hc` hidden column tiles?  (SiLU, fp32 arithmetic, the LDS row stride the
+// instance was compiled for -- i.e. no layer wider than the hidden ones; RolloutArgs::generic_only == 1 forbids it, 2 allows it)
+inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int hc) {
+    return ra.generic_only != 1 && md.precision == HIPETS_PREC_F32 && md.activation == HIPETS_ACT_SILU && md.hidC == hc && md.ld == lean_ld(hc, hc);
+}
+
+// Shape-specialised ("lean") fp32 instances per row-tile count R: X(hidden column tiles, output column tiles, reward fn, termination
+// fn, obs preprocessing); all of them SiLU, f64 normaliser, stochastic GaussianMLP with in-kernel sampling.  R follows the cost
+// model's choice for the configuration (hipets.hip choose_R, which in turn knows this table: lean_shape_exists):
+//   BASELINE.json: cfg1 cartpole R = 1, cfg2 / cfg3 R = 3 (a rank's shard of a strong-scaled plan: 1, 2), cfg4 R = 3 at its first
+//   iteration and 2 / 4 as the iCEM population decays, cfg4' Humanoid-v4 R = 2 (small batches 1; KSpec::WIDE), cfg5 (2500 row tiles) 2;
+//   the workloads the reference ships (round 4): pets_halfcheetah (conf/overrides/pets_halfcheetah.yaml: obs 18 through
+//   HalfCheetahEnv.preprocess_fn, pop 400 x 20) R = 2 in DEVICE mode, 1 in FAST mode; pets_cartpole (pop 350 x 20) R = 1, 2;
+//   pets_cartpole_paper_version (cartpole_pets reward + CartPoleEnv.preprocess_fn, pop 500 x 20) R = 3.
+#define HIPETS_LEAN_SHAPES_R1(X)                                                                                                               \
+    X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
+#define HIPETS_LEAN_SHAPES_R2(X)                                                                                                               \
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
+    X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
+    X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE)
+#define HIPETS_LEAN_SHAPES_R3(X)                                                                                                               \
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS)
+#define HIPETS_LEAN_SHAPES_R4(X) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE)
+
+// the model-side facts every lean fp32 instance shares (the call-side ones: lean_call below)
+inline bool lean_model(const ModelDev& md) {
+    return md.precision == HIPETS_PREC_F32 && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 && !md.deterministic &&
+           md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1;
+}
+
+// is there a lean fp32 instance of this model's shape for R row tiles? (what the launcher of rollout_r<R>.hip will find; the cost
+// model prices a (shape, R) pair with an instance lower than one that runs the hidden-static or the generic kernel)
+inline bool lean_shape_exists(const ModelDev& md, const int R) {
+    if (!lean_model(md)) return false;
+#define HIPETS_HAS_SHAPE(HC, OC, RW, TM, OB) \
+    if (md.hidC == HC && md.outC == OC && md.reward_fn == RW && md.term_fn == TM && md.obs_process == OB && md.ld == lean_ld(HC, OC)) return true;
+    switch (R) {
+        case 1: HIPETS_LEAN_SHAPES_R1(HIPETS_HAS_SHAPE) break;
+        case 2: HIPETS_LEAN_SHAPES_R2(HIPETS_HAS_SHAPE) break;
+        case 3: HIPETS_LEAN_SHAPES_R3(HIPETS_HAS_SHAPE) break;
+        case 4: HIPETS_LEAN_SHAPES_R4(HIPETS_HAS_SHAPE) break;
+        default: break;
+    }
+#undef HIPETS_HAS_SHAPE
+    return false;
+}
+
+// does the call use nothing a lean instance compiled out? (KSpec in rollout.hpp lists what that is; the obs preprocessing is part
+// of an instance's shape since round 4)
 inline bool lean_call(const ModelDev& md, const RolloutArgs& ra) {
-    return !ra.generic_only && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 && md.obs_process == HIPETS_OBS_NONE &&
+    return !ra.generic_only && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 &&
            !md.deterministic && md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && !ra.eps && ra.use_philox &&
 #if defined(HIPETS_STEP_TRACE) || (defined(HIPETS_LEAN_PROF) && HIPETS_LEAN_PROF)
            !ra.trace_next_obs && !ra.trace_rewards && ra.pop_env == 0 && !ra.init_states && !ra.write_back;  // the stamps go to phase_cycles

@@ -110,7 +110,8 @@ struct RolloutArgs {
     int pop_env;               // FAST batched planning: candidates per environment (candidate c starts from s0[c / pop_env]); 0 = one env
     const float* init_states;  // FAST: optional per-row initial states [B,obs] (ModelEnv.step path) instead of tiling s0
     int write_back;            // FAST: also write the final state [B,obs] to `state` and the done flags to `term`
-    int generic_only;          // never pick a shape-specialised (lean) kernel instance (hipets_rollout_opts.generic_kernel)
+    int generic_only;          // hipets_rollout_opts.generic_kernel: 1 = only the fully generic kernel instance; 2 = no shape-specialised
+                               // (lean) instance, but the hidden-static one (KSpec::HID_STATIC) where the model has its width
     int wide_lds;              // the host sized the LDS (and chose R) for the KSpec::WIDE layout: the launcher runs that instance or fails
     // DEVICE mode, persistent form (all workgroups co-resident, ONE launch for the horizon): rows change workgroups every step
     // through `exchange`, a [B][obs_dim + 2] table of 8-byte {value bits, step tag} granules (state dims, running total,
@@ -534,7 +535,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // Pin every accumulator's initial value HERE: to the compiler an asm MFMA is an ordinary reader of its C operand, so it may
     // sink the (VALU) initialisation -- a copy of the bias, the zeros of the odd-k-step accumulators -- down to just in front of
     // the first MFMA that uses the register, inside a k-step, behind that k-step's s_nop: a VALU write followed at once by an MFMA
-    // reading it as SrcC (hazard (1) below; found in the ISA of the cfg4 instances by tests/test_isa_hazards.py, where it returned
+    // reading it as SrcC (hazard (1) below; found in the ISA of the cfg4 instances by __graft_entry__.scan_isa_hazards (tests/test_abi.py), where it returned
     // wrong sums).  An empty asm that "modifies" the register makes the value opaque: it must be complete before this point.
     auto pin = [](f32x4& v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); };
 #pragma unroll
@@ -1080,7 +1081,14 @@ struct KSpec {
     static constexpr int LD = (HIDC_ >= 0 && PREC_ == HIPETS_PREC_F32) ? lean_ld(HIDC_, WIDE ? HIDC_ : OUTC_) : -1;  // compile-time LDS row stride (fp32 lean instances)
     static constexpr int ACT = ACT_, HIDC = HIDC_, OUTC = OUTC_, NORM = NORM_, OBSP = OBSP_, REW = REW_, TERM = TERM_, KMODE = KMODE_;
     static constexpr int PREC = PREC_;  // HIPETS_PREC_F32 (fp32 MFMA) or HIPETS_PREC_BF16X3 (lean instances only)
-    static constexpr bool LEAN = HIDC_ >= 0;
+    static constexpr bool LEAN = HIDC_ >= 0 && OUTC_ >= 0;
+    // HIDDEN-STATIC instances (HIDC_ >= 0, everything else decided at run time): what ANY model with that hidden width gets --
+    // the reference's default is 200 = 13 column tiles (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8), whatever its
+    // environment's obs preprocessing, reward / termination functions, normaliser, output width or propagation method.  The ops
+    // that carry > 90 % of a step's FLOPs (every op whose N is the hidden width) run exactly like in the shape-specialised
+    // instances: per-wave (CT, EX) through one branch, compile-time LDS stride, interleaved fragment loads, unrolled k loops where
+    // the register file allows; the output layer and every elementwise phase stay the generic kernel's.
+    static constexpr bool HID_STATIC = HIDC_ >= 0 && OUTC_ < 0;
     // FUSE (lean fp32 instances): the output layer runs on the "head pair" pack and its accumulators go straight into the
     // step's tail -- sampling, delta, next state, hand-over publication, reward / termination / totals and the next step's
     // normalised model input happen in registers in the output layer's own barrier interval (5 barriers per step instead
@@ -1088,10 +1096,12 @@ struct KSpec {
     // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
     static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && (OUTC_ <= kSplMaxTiles || WIDE);
     static constexpr bool SPL_OUT = OUTC_ >= 0 && OUTC_ <= kSplMaxTiles;  // the output layer sums even / odd k-steps separately (wave_gemm SPL)
-    static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE) &&
+    static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS) &&
                             (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID)),
                   "fused tail: the reward / termination lane sees dims 0..3 of its row");
-    static_assert(!FUSE || (NORM_ == HIPETS_NORM_F64 && OBSP_ == HIPETS_OBS_NONE), "fused tail: f64 normaliser, no obs preprocessing");
+    // obs preprocessing in the fused tail (round 4): the lane that holds the trig dim writes its sin and cos columns (ObsMap)
+    static_assert(!FUSE || (NORM_ == HIPETS_NORM_F64 && (OBSP_ == HIPETS_OBS_NONE || !WIDE)), "fused tail: f64 normaliser; WIDE instances: no obs preprocessing");
+    static_assert(!FUSE || OBSP_ == HIPETS_OBS_NONE || OBSP_ == HIPETS_OBS_HALFCHEETAH || OBSP_ == HIPETS_OBS_CARTPOLE_PETS, "unknown obs preprocessing");
 };
 
 // can an op with CS column tiles take part in the cross-layer prefetch? (one wave_gemm per wave, see linear_op)
@@ -1165,6 +1175,13 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
         if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, S::WIDE ? md.ld_in : 0);
         else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
         else linear_op<R, S::ACT, S::OUTC, false, NoTail, S::LD, (S::OUTC <= kSplMaxTiles), kHidChunks>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
+    } else if constexpr (S::HID_STATIC) {
+        constexpr int kHidChunks = (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1;
+        if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
+        else if (lm.Np / kTile <= kSplMaxTiles)  // the output layer: the generic instance's dispatch, the SAME summation rule (SPL)
+            linear_op<R, S::ACT, -1, false, NoTail, -1, true>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
+        else linear_op<R, S::ACT>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
     } else {
         // the output layer of up to kSplMaxTiles column tiles: SPL (the SAME rule in the shape-specialised branch above)
         if (l == md.n_layers - 1 && lm.Np / kTile <= kSplMaxTiles)
@@ -1182,6 +1199,23 @@ __device__ __forceinline__ void mlp_output_layer_fused(const ModelDev& md, const
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff_pairs;
     linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
 }
+
+// obs_process_fn seen from the PRODUCER of an observation dim (the fused tail, the straight form's collect phase: both hold a pair
+// of raw dims in registers and write the next step's input image themselves): which input column does dim d feed, and which dim
+// enters as sin / cos?  halfcheetah (env/pets_halfcheetah.py:91-113): [s1, sin s2, cos s2, s3:] -- dim 0 feeds nothing;
+// cartpole_pets (env/pets_cartpole.py:78-101): [sin s1, cos s1, s0, s2:] -- one column more than dims.
+template <int OBSP>
+struct ObsMap {
+    static constexpr int kTrigDim = OBSP == HIPETS_OBS_HALFCHEETAH ? 2 : (OBSP == HIPETS_OBS_CARTPOLE_PETS ? 1 : -1);  // enters as sin and cos
+    static constexpr int kSinCol = OBSP == HIPETS_OBS_HALFCHEETAH ? 1 : 0;
+    static constexpr int kCosCol = OBSP == HIPETS_OBS_HALFCHEETAH ? 2 : 1;
+    // column of dim d (the sin column for the trig dim), -1 = the dim is not a model input
+    __device__ static __forceinline__ int col(const int d) {
+        if constexpr (OBSP == HIPETS_OBS_HALFCHEETAH) return d == 0 ? -1 : (d == 1 ? 0 : (d == 2 ? 1 : d));
+        else if constexpr (OBSP == HIPETS_OBS_CARTPOLE_PETS) return d == 0 ? 2 : (d == 1 ? 0 : d + 1);
+        else return d;
+    }
+};
 
 // obs_process_fn(obs)[i] (mbrl/env/pets_halfcheetah.py:91-113, pets_cartpole.py:78-101)
 __device__ __forceinline__ float processed_obs(const float* s, int i, int mode) {
@@ -1809,10 +1843,11 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     const int rid = rows[gs[q]];
                     if (rid >= 0) { src[q] = ra.exchange + (size_t)rid * NV + 2 * gv[q]; live[q] = true; }
                 }
-                // the normaliser constants of the pair's two dims: requested now, used when the pair has arrived
-                const int d = soft[q] ? 0 : 2 * gv[q], d1 = min(d + 1, md.obs_dim - 1);
-                nm[q][0] = sm.nmean[d]; nm[q][1] = sm.nmean[d1];
-                ns[q][0] = sm.nstd[d]; ns[q][1] = sm.nstd[d1];
+                // the normaliser constants of the input columns the pair's two dims feed (ObsMap): requested now, used when the pair has arrived
+                const int d = soft[q] ? 0 : 2 * gv[q];
+                const int i0 = max(0, min(ObsMap<S::OBSP>::col(d), md.obs_in - 1)), i1 = max(0, min(ObsMap<S::OBSP>::col(d + 1), md.obs_in - 1));
+                nm[q][0] = sm.nmean[i0]; nm[q][1] = sm.nmean[i1];
+                ns[q][0] = sm.nstd[i0]; ns[q][1] = sm.nstd[i1];
             }
             const long long t_poll = wall_clock64();
             for (int spins = 0;; ++spins) {
@@ -1840,13 +1875,24 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             for (int q = 0; q < kG; ++q)
                 if (gs[q] >= 0) {
                     if (!soft[q]) {
+                        using OM = ObsMap<S::OBSP>;
                         const int d = 2 * gv[q];
                         const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
+                        float x0 = v0, x1 = v1;
+                        if constexpr (OM::kTrigDim >= 0) {
+                            if (d == OM::kTrigDim || d + 1 == OM::kTrigDim) {  // this thread holds the dim that enters as sin and cos (processed_obs's sinf / cosf)
+                                const float tv = d == OM::kTrigDim ? v0 : v1;
+                                const float sv = sinf(tv), cv = cosf(tv);
+                                if (d == OM::kTrigDim) x0 = sv; else x1 = sv;
+                                dst[gs[q] * ld_in + lds_col(OM::kCosCol)] = live[q] ? (float)(((double)cv - sm.nmean[OM::kCosCol]) * sm.nstd[OM::kCosCol]) : 0.f;
+                            }
+                        }
+                        const int c0 = OM::col(d), c1 = OM::col(d + 1);
                         sm.state[gs[q] * md.obs_dim + d] = v0;
-                        dst[gs[q] * ld_in + lds_col(d)] = live[q] ? (float)(((double)v0 - nm[q][0]) * ns[q][0]) : 0.f;
+                        if (c0 >= 0) dst[gs[q] * ld_in + lds_col(c0)] = live[q] ? (float)(((double)x0 - nm[q][0]) * ns[q][0]) : 0.f;
                         if (d + 1 < md.obs_dim) {
                             sm.state[gs[q] * md.obs_dim + d + 1] = v1;
-                            dst[gs[q] * ld_in + lds_col(d + 1)] = live[q] ? (float)(((double)v1 - nm[q][1]) * ns[q][1]) : 0.f;
+                            if (c1 >= 0) dst[gs[q] * ld_in + lds_col(c1)] = live[q] ? (float)(((double)x1 - nm[q][1]) * ns[q][1]) : 0.f;
                         }
                     } else if (src[q]) {
                         sm.pend[gs[q]] = 1;  // not there yet: the next tail fetches the pair
@@ -1926,7 +1972,10 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 q.mxA = sm.maxlv[dA]; q.mxB = sm.maxlv[dB]; q.mnA = sm.minlv[dA]; q.mnB = sm.minlv[dB];
                 q.pA = sm.state[s * md.obs_dim + oA]; q.pB = sm.state[s * md.obs_dim + oB];
                 q.ndA = sm.nodelta[oA]; q.ndB = sm.nodelta[oB];
-                q.nmA = sm.nmean[oA]; q.nmB = sm.nmean[oB]; q.nsA = sm.nstd[oA]; q.nsB = sm.nstd[oB];
+                // the normaliser constants of the input COLUMNS the two dims feed (obs preprocessing moves them: ObsMap)
+                using OM = ObsMap<S::OBSP>;
+                const int iA = max(0, min(OM::col(d0), md.obs_in - 1)), iB = max(0, min(OM::col(d0 + 1), md.obs_in - 1));
+                q.nmA = sm.nmean[iA]; q.nmB = sm.nmean[iB]; q.nsA = sm.nstd[iA]; q.nsB = sm.nstd[iB];
             };
             auto tail_unit = [&](const FusedSlot& q, const f32x4 a, const int c, const int r) __attribute__((always_inline)) {
                 const int g = lane >> 4, j = lane & 15;
@@ -1956,9 +2005,23 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const float vB = predB + (addB ? pB : 0.f);
                 sm.state[okA ? s * md.obs_dim + d0 : (int)(sm.dump - sm.state)] = vA;
                 sm.state[okB ? s * md.obs_dim + d0 + 1 : (int)(sm.dump - sm.state) + 1] = vB;
-                if (write_input) {  // wave-uniform; build_input_impl's f64 form, OBSP none: input column d = obs dim d
-                    nxt[okA ? s * ld_k + lds_col(d0) : (int)(sm.dump - nxt) + 2] = (float)(((double)vA - nmA) * nsA);
-                    nxt[okB ? s * ld_k + lds_col(d0 + 1) : (int)(sm.dump - nxt) + 3] = (float)(((double)vB - nmB) * nsB);
+                if (write_input) {  // wave-uniform; build_input_impl's f64 form (the columns ObsMap names: input column d = obs dim d without preprocessing)
+                    using OM = ObsMap<S::OBSP>;
+                    const int cA = OM::col(d0), cB = OM::col(d0 + 1);
+                    float xA = vA, xB = vB;
+                    if constexpr (OM::kTrigDim >= 0) {
+                        if (c == 0) {  // wave-uniform: the trig dim lives in column tile 0.  Same sinf / cosf as processed_obs: same bits as the generic kernel
+                            const bool trigA = d0 == OM::kTrigDim, trigB = d0 + 1 == OM::kTrigDim;
+                            const float tv = trigA ? vA : vB;
+                            const float sv = sinf(tv), cv = cosf(tv);
+                            xA = trigA ? sv : xA;
+                            xB = trigB ? sv : xB;
+                            const bool okT = (trigA && okA) || (trigB && okB);
+                            nxt[okT ? s * ld_k + lds_col(OM::kCosCol) : (int)(sm.dump - nxt) + 1] = (float)(((double)cv - sm.nmean[OM::kCosCol]) * sm.nstd[OM::kCosCol]);
+                        }
+                    }
+                    nxt[(okA && cA >= 0) ? s * ld_k + lds_col(max(cA, 0)) : (int)(sm.dump - nxt) + 2] = (float)(((double)xA - nmA) * nsA);
+                    nxt[(okB && cB >= 0) ? s * ld_k + lds_col(max(cB, 0)) : (int)(sm.dump - nxt) + 3] = (float)(((double)xB - nmB) * nsB);
                 }
                 const unsigned pubA = okA ? __float_as_uint(vA) : 0u, pubB = okB ? __float_as_uint(vB) : 0u;
                 // persistent DEVICE form: the row's next owner waits for these values.  Under a real (divergent) predicate: redirecting

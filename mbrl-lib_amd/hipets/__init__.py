@@ -4,7 +4,7 @@ Public names follow mbrl-lib so the stock Hydra configs only swap ``_target_``:
 ``hipets.TrajectoryOptimizerAgent``, ``hipets.CEMOptimizer`` ... or, on a stock agent,
 ``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))``.
 """
-from ._lib import HipetsError, LIB_PATH  # noqa: F401
+from ._lib import ERR_INVALID_ARGUMENT, ERR_NONE, ERR_RUNTIME, ERR_TIMEOUT, HipetsError, LIB_PATH  # noqa: F401
 from .model import (  # noqa: F401
     ModelSpec,
     PlaNetSpec,

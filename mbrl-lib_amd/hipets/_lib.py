@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HIPETS_LIB selects another build of the SAME library (kernel-variant experiments under profiles/); there is no fallback
 LIB_PATH = os.environ.get("HIPETS_LIB") or os.path.join(_HERE, "libhipets.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 8
 
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -98,6 +98,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "hipets_abi_version": (C.c_int, []),
     "hipets_last_error": (C.c_char_p, []),
+    "hipets_last_error_kind": (C.c_int, []),
     "hipets_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "hipets_destroy": (None, [_P]),
     "hipets_set_model": (C.c_int, [_P, C.POINTER(ModelDesc), _P]),
@@ -114,6 +115,7 @@ SYMBOLS = {
     "hipets_set_plan_trace": (C.c_int, [_P, C.POINTER(PlanTrace)]),
     "hipets_cem_sample": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_cem_refit": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hipets_cem_refit_elites": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, _P, _P, _P]),
     "hipets_gather_rows": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "hipets_mppi_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_mppi_update": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P]),
@@ -134,6 +136,10 @@ SYMBOLS = {
     "hipets_comm_destroy": (C.c_int, [_P]),
     "hipets_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_plan_cem_sharded": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
+    "hipets_plan_mppi_sharded": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _P, _P, _P, _P, C.c_int32,
+                                           C.c_uint64, C.c_uint64, _P]),
+    "hipets_plan_icem_sharded": (C.c_int, [_P, C.POINTER(IcemParams), _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_uint64, C.c_uint64,
+                                           _P, _P]),
     "hipets_planet_set_model": (C.c_int, [_P, C.POINTER(PlanetDesc), _P]),
     "hipets_planet_rollout": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PlanetOpts), _P, _P]),
     "hipets_plan_planet_cem": (C.c_int, [_P, C.POINTER(CemParams), _P, _P, _P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
@@ -147,8 +153,16 @@ _lib = None
 COMM_ID_BYTES = 128
 
 
+ERR_NONE, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_TIMEOUT = 0, 1, 2, 3
+
+
 class HipetsError(RuntimeError):
-    pass
+    """A failed libhipets call.  ``kind`` = hipets_last_error_kind(): ERR_INVALID_ARGUMENT (the library refused the arguments: the
+    same on every rank that passed them), ERR_RUNTIME (a HIP / RCCL call, an allocation or a launch failed), ERR_TIMEOUT."""
+
+    def __init__(self, message="", kind: int = ERR_INVALID_ARGUMENT):
+        super().__init__(message)
+        self.kind = kind
 
 
 def load():
@@ -174,4 +188,5 @@ def load():
 
 def check(rc: int):
     if rc != 0:
-        raise HipetsError(load().hipets_last_error().decode())
+        lib = load()
+        raise HipetsError(lib.hipets_last_error().decode(), lib.hipets_last_error_kind())

@@ -10,7 +10,7 @@ ranks with no broadcast.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is us
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 import torch
@@ -80,12 +80,14 @@ def is_distributed() -> bool:
 
 def init_engine_comm(engine, group=None):
     """Give ``engine`` its own RCCL communicator over the ranks of ``group`` (hipets_comm_init): rank 0 creates the id,
-    torch.distributed only carries its 128 bytes.  Afterwards ``Engine.plan_cem_sharded`` runs the whole sharded plan as one
-    device-side loop per rank (no per-iteration host work)."""
+    torch.distributed only carries its 128 bytes.  Afterwards the optimizer classes of ``hipets.planning`` run their fused plans
+    SHARDED over these ranks (``TrajectoryOptimizerAgent.act`` needs no other change): one device-side loop per rank, one
+    ncclAllGather of the candidates' returns per iteration, no per-iteration host work."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     box = [engine.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     engine.comm_init(box[0], rank, world)
+    engine.comm_group = group  # the process group the ranks agree over (plan_*_sharded below)
     return engine
 
 
@@ -105,33 +107,34 @@ def _worst_status(code: int, group=None) -> int:
 _OK, _RUNTIME_FAILURE, _REJECTED = 0, 1, 2
 
 
-def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, seed: int = 0, plan_id: int = 0, group=None):
-    """``Engine.plan_cem_sharded`` with the failure policy of SURVEY.md section 5.  The sharded plan runs when the engine has a
-    communicator; afterwards its stream is synchronised, every rank asks its engine whether a rollout was cut short
-    (``check_async_error``) and the ranks AGREE (one host-side all-reduce over ``group`` when torch.distributed is up) on
-    whether the plan stands.  If any rank had a runtime failure -- RCCL reported an error while the plan was enqueued, a
-    persistent rollout timed out, a HIP call or an allocation failed -- every rank drops its communicator, warns, and plans
-    the WHOLE population on its own GPU (``hipets_plan_cem``: same sampler streams, so all ranks still return the same
-    valid plan for the observation) instead of failing the control loop.  Arguments the library rejects (a population the
-    shards cannot hold, a wrong action width: identical on every rank) still raise.  Returns ``(plan, used_fallback)``."""
+def run_sharded(engine, sharded_call: Callable, single_call: Callable, group=None, restore: Optional[Callable] = None):
+    """The failure policy of SURVEY.md section 5 around one sharded plan (CEM, MPPI or iCEM).  ``sharded_call()`` runs when the
+    engine has a communicator; afterwards its stream is synchronised, every rank asks its engine whether a rollout was cut
+    short (``check_async_error``) and the ranks AGREE (one host-side all-reduce over ``group`` when torch.distributed is up)
+    on whether the plan stands.  If any rank had a runtime failure -- RCCL reported an error while the plan was enqueued, a
+    persistent rollout timed out, a HIP call or an allocation failed: ``HipetsError.kind`` (hipets_last_error_kind), not the
+    wording of the message, says so -- every rank drops its communicator, warns, puts back what the attempt changed in place
+    (``restore()``: MPPI's mean, iCEM's elites) and runs ``single_call()``: the WHOLE population on its own GPU with the same
+    sampler streams, so all ranks still return the same valid plan for the observation instead of failing the control loop.
+    Arguments the library rejects (a population the shards cannot hold, a wrong action width: identical on every rank) still
+    raise.  Returns ``(result, used_fallback)``."""
     import warnings
 
-    from ._lib import HipetsError
+    from ._lib import ERR_INVALID_ARGUMENT, HipetsError
 
     if engine.comm_world > 1:
-        code, reason, plan, error = _OK, None, None, None
+        code, reason, result, error = _OK, None, None, None
         try:
-            plan = engine.plan_cem_sharded(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id)
+            result = sharded_call()
             engine.synchronize()
             if engine.check_async_error():
                 code, reason = _RUNTIME_FAILURE, "a persistent DEVICE-mode rollout timed out"
         except HipetsError as exc:
             error, reason = exc, str(exc)
-            runtime = any(k in reason for k in ("RCCL", "communicator", "failed:", "hipMalloc", "launch failed"))
-            code = _RUNTIME_FAILURE if runtime else _REJECTED
+            code = _REJECTED if getattr(exc, "kind", ERR_INVALID_ARGUMENT) == ERR_INVALID_ARGUMENT else _RUNTIME_FAILURE
         worst = _worst_status(code, group)
         if worst == _OK:
-            return plan, False
+            return result, False
         if worst == _REJECTED:
             raise error if code == _REJECTED else HipetsError("a peer rank rejected the arguments of the sharded plan")
         warnings.warn(f"hipets: sharded plan failed on rank {engine.comm_rank} or a peer ({reason or 'peer failure'}); "
@@ -140,4 +143,38 @@ def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, s
             engine.comm_destroy()
         except HipetsError:
             engine.comm_world, engine.comm_rank = 1, 0
-    return engine.plan_cem(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), True
+        if restore is not None:
+            restore()
+    return single_call(), True
+
+
+def plan_cem_sharded(engine, params, x0, lower, upper, s0, num_particles: int, seed: int = 0, plan_id: int = 0, group=None):
+    """``Engine.plan_cem_sharded`` under :func:`run_sharded`'s failure policy (fallback: ``Engine.plan_cem`` of the whole
+    population).  Returns ``(plan, used_fallback)``."""
+    return run_sharded(engine,
+                       lambda: engine.plan_cem_sharded(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id),
+                       lambda: engine.plan_cem(params, x0, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id), group)
+
+
+def plan_mppi_sharded(engine, pop: int, H: int, A: int, num_iterations: int, gamma: float, beta: float, mean: torch.Tensor, lower, upper, s0,
+                      num_particles: int, seed: int = 0, plan_id: int = 0, group=None):
+    """``Engine.plan_mppi_sharded`` (hipets_plan_mppi_sharded) under :func:`run_sharded`'s failure policy.  ``mean`` -- the
+    optimizer's persistent mean -- is shifted and refined IN PLACE; a failed sharded attempt is undone before the single-GPU plan
+    runs.  Returns ``(mean, used_fallback)``."""
+    before = mean.clone()
+    return run_sharded(engine,
+                       lambda: engine.plan_mppi_sharded(pop, H, A, num_iterations, gamma, beta, mean, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id),
+                       lambda: engine.plan_mppi(pop, H, A, num_iterations, gamma, beta, mean, lower, upper, s0, num_particles, seed=seed, plan_id=plan_id),
+                       group, restore=lambda: mean.copy_(before))
+
+
+def plan_icem_sharded(engine, params, x0, lower, upper, elite: torch.Tensor, has_elite: bool, s0, num_particles: int, seed: int = 0,
+                      plan_id: int = 0, keep_idx=None, group=None):
+    """``Engine.plan_icem_sharded`` (hipets_plan_icem_sharded) under :func:`run_sharded`'s failure policy.  ``elite`` -- the
+    optimizer's persistent elite set -- is overwritten by every iteration; a failed sharded attempt is undone before the single-GPU
+    plan runs.  Returns ``(plan, used_fallback)``."""
+    before = elite.clone()
+    return run_sharded(engine,
+                       lambda: engine.plan_icem_sharded(params, x0, lower, upper, elite, has_elite, s0, num_particles, seed=seed, plan_id=plan_id, keep_idx=keep_idx),
+                       lambda: engine.plan_icem(params, x0, lower, upper, elite, has_elite, s0, num_particles, seed=seed, plan_id=plan_id, keep_idx=keep_idx),
+                       group, restore=lambda: elite.copy_(before))

@@ -68,6 +68,7 @@ class Engine:
         self.spec: Optional[ModelSpec] = None
         self.planet_spec = None
         self.comm_world, self.comm_rank = 1, 0
+        self.comm_group = None  # torch.distributed group of the communicator's ranks (hipets.dist.init_engine_comm)
         self.plan_mode = "fast"
         self._trace = None
         self._keep = []  # device tensors that must outlive async set_model work
@@ -142,7 +143,7 @@ class Engine:
                 trace_next_obs: Optional[torch.Tensor] = None, trace_rewards: Optional[torch.Tensor] = None,
                 rows_per_group: int = 0, out: Optional[torch.Tensor] = None,
                 phase_cycles: Optional[torch.Tensor] = None, n_env: int = 1,
-                members: Optional[torch.Tensor] = None, generic_kernel: bool = False) -> torch.Tensor:
+                members: Optional[torch.Tensor] = None, generic_kernel=False) -> torch.Tensor:
         """``members`` (EXACT mode): int64 [H, B] (random_model) or [B] (fixed_model) active-member slot of every row: the
         reference's ``torch.randint`` draws for BasicEnsemble models (basic_ensemble.py:122-129, 255-260), or any
         ``propagate_from_indices``-style assignment (util/math.py:180-196) for GaussianMLP models (no batch % members rule)."""
@@ -163,7 +164,7 @@ class Engine:
         B = pop * num_particles
         o = RolloutOpts()
         o.n_env = int(n_env)
-        o.generic_kernel = int(bool(generic_kernel))
+        o.generic_kernel = int(generic_kernel)  # False / True (1: fully generic instance only) / 2 (hidden-static allowed, shape-specialised not)
         if mode not in _lib.MODES:
             raise ValueError("mode must be 'exact', 'fast' or 'device'")
         o.mode = _lib.MODES[mode]
@@ -368,7 +369,9 @@ class Engine:
                                                    _ptr(population), _stream(dev)))
         return population
 
-    def cem_refit(self, p: CemParams, values, population, mu, dispersion, best_value, best_solution, elite_idx=None):
+    def cem_refit(self, p: CemParams, values, population, mu, dispersion, best_value, best_solution, elite_idx=None, elites=None):
+        """``elites`` int32 [elite_num] (device): refit on THESE candidates, best first, instead of the kernel's own top-k
+        (hipets_cem_refit_elites: the reference-order parity mode passes torch.topk's indices, ties and all)."""
         dev = self.device
         D = p.horizon * p.act_dim
         _check_dev(values, torch.float32, dev, "values", (p.population_size,))
@@ -378,6 +381,14 @@ class Engine:
         _check_dev(best_value, torch.float32, dev, "best_value", (1,))
         if elite_idx is not None:
             _check_dev(elite_idx, torch.int32, dev, "elite_idx", (p.elite_num,))
+        if elites is not None:
+            _check_dev(elites, torch.int32, dev, "elites", (p.elite_num,))
+            with torch.cuda.device(dev):
+                _lib.check(self._lib.hipets_cem_refit_elites(self._h, C.byref(p), _ptr(values), _ptr(population), _ptr(elites), _ptr(mu),
+                                                             _ptr(dispersion), _ptr(best_value), _ptr(best_solution), _stream(dev)))
+            if elite_idx is not None:
+                elite_idx.copy_(elites)
+            return
         with torch.cuda.device(dev):
             _lib.check(self._lib.hipets_cem_refit(self._h, C.byref(p), _ptr(values), _ptr(population), _ptr(mu), _ptr(dispersion),
                                                   _ptr(best_value), _ptr(best_solution), _ptr(elite_idx), _stream(dev)))
@@ -531,7 +542,7 @@ class Engine:
 
     def comm_destroy(self):
         _lib.check(self._lib.hipets_comm_destroy(self._h))
-        self.comm_world, self.comm_rank = 1, 0
+        self.comm_world, self.comm_rank, self.comm_group = 1, 0, None
 
     def comm_info(self) -> tuple:
         """(rank, world size) as the communicator itself reports them (hipets_comm_info)."""
@@ -557,6 +568,47 @@ class Engine:
             _lib.check(self._lib.hipets_plan_cem_sharded(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper),
                                                          s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
                                                          int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
+        return out
+
+    def plan_mppi_sharded(self, pop: int, H: int, A: int, num_iterations: int, gamma: float, beta: float, mean: torch.Tensor, lower,
+                          upper, s0: np.ndarray, num_particles: int, seed: int = 0, plan_id: int = 0) -> torch.Tensor:
+        """hipets_plan_mppi over all ranks of the communicator (identical arguments on every rank; ``mean`` in place)."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        for n_, t in (("mean", mean), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, (H, A))
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_mppi_sharded(self._h, pop, H, A, num_iterations, float(gamma), float(beta), _ptr(mean), _ptr(lower),
+                                                          _ptr(upper), s0.ctypes.data_as(C.c_void_p), num_particles, int(seed) & (2**64 - 1),
+                                                          int(plan_id) & (2**64 - 1), _stream(dev)))
+        return mean
+
+    def plan_icem_sharded(self, p: "_lib.IcemParams", x0, lower, upper, elite: torch.Tensor, has_elite: bool, s0: np.ndarray,
+                          num_particles: int, seed: int = 0, plan_id: int = 0, keep_idx: Optional[torch.Tensor] = None,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """hipets_plan_icem over all ranks of the communicator (identical arguments on every rank; ``elite`` in place)."""
+        if self.spec is None:
+            raise HipetsError("Engine.set_model() has not been called")
+        dev = self.device
+        shp = (p.horizon, p.act_dim)
+        for n_, t in (("x0", x0), ("lower", lower), ("upper", upper)):
+            _check_dev(t, torch.float32, dev, n_, shp)
+        _check_dev(elite, torch.float32, dev, "elite", numel=p.elite_num * p.horizon * p.act_dim)
+        if keep_idx is not None:
+            _check_dev(keep_idx, torch.int32, dev, "keep_idx", numel=p.num_iterations * p.keep_elite_size)
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
+        if s0.shape[0] != self.spec.obs_dim:
+            raise ValueError(f"initial_state has {s0.shape[0]} values, expected {self.spec.obs_dim}")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.hipets_plan_icem_sharded(self._h, C.byref(p), _ptr(x0), _ptr(lower), _ptr(upper), _ptr(elite), int(bool(has_elite)),
+                                                          _ptr(keep_idx) if keep_idx is not None else None, s0.ctypes.data_as(C.c_void_p),
+                                                          num_particles, int(seed) & (2**64 - 1), int(plan_id) & (2**64 - 1), _ptr(out), _stream(dev)))
         return out
 
     # ---- PlaNet latent planner (SURVEY.md 8f row 4) -----------------------------------------------

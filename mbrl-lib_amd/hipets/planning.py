@@ -21,6 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import dist as hdist
 from ._lib import HipetsError, IcemParams
 from .engine import Engine
 from .model import (ModelSpec, PlaNetSpec, UnsupportedModelError, is_planet_model, model_version, planet_version,
@@ -539,6 +540,16 @@ def _default_seed(seed: Optional[int]) -> int:
     return int(seed) & (2**63 - 1)
 
 
+def _reference_elites(values: torch.Tensor, elite_num: int, device) -> torch.Tensor:
+    """The elite indices the reference's optimizers pick on a CPU device (trajectory_opt.py:178-179, 467-470): NaN -> -1e-10, then
+    ``torch.topk`` -- whose order among EQUAL values is an artefact of its partial sort.  The 0 / 1 rewards of the cartpole family
+    (env/reward_fns.py:10-13, 27-30) tie dozens of candidates at the elite boundary, so a seed-identical replay
+    (``sampler='torch'``: it synchronises with the host anyway) has to ask the same routine.  int32 indices on ``device``."""
+    v = values.detach().to("cpu", torch.float32).clone()
+    v[v.isnan()] = -1e-10
+    return torch.topk(v, int(elite_num)).indices.to(torch.int32).to(device).contiguous()
+
+
 def _reference_noise(shape, clipped_normal: bool) -> torch.Tensor:
     """The standard-normal draws of CEMOptimizer._sample_population on a CPU device, from torch's global generator:
     ``randn`` for the clipped-normal branch (trajectory_opt.py:116-117), otherwise mbrl.util.math.truncated_normal_
@@ -622,6 +633,9 @@ class CEMOptimizer(Optimizer):
                 return self.engine.plan_planet_cem(self._params, x0, self.lower_bound, self.upper_bound, latent0, belief0,
                                                    fused.num_particles, seed=seed, plan_id=self.calls)
             _prepare_fused(fused, [self.population_size])
+            if self.engine.comm_world > 1:  # the engine has a communicator (hipets.dist.init_engine_comm): the ranks share the population
+                return hdist.plan_cem_sharded(self.engine, self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
+                                              fused.num_particles, seed=seed, plan_id=self.calls, group=self.engine.comm_group)[0]
             return self.engine.plan_cem(self._params, x0, self.lower_bound, self.upper_bound, obj_fun.obs,
                                         fused.num_particles, seed=seed, plan_id=self.calls)
         p = self._params
@@ -641,7 +655,8 @@ class CEMOptimizer(Optimizer):
                 callback(population, values, i)
             if values.device != self.device or values.dtype != torch.float32 or not values.is_contiguous():
                 values = values.to(device=self.device, dtype=torch.float32).contiguous()
-            self.engine.cem_refit(p, values, population, mu, dispersion, best_value, best_solution)
+            elites = _reference_elites(values, self.elite_num, self.device) if self.sampler == "torch" else None
+            self.engine.cem_refit(p, values, population, mu, dispersion, best_value, best_solution, elites=elites)
         return mu if self.return_mean_elites else best_solution
 
 
@@ -685,6 +700,11 @@ class MPPIOptimizer(Optimizer):
         if fused is not None and callback is None and noise is None and not kwargs.get("force_generic", False):
             _prepare_fused(fused, [pop])
             self.mean = self.mean.contiguous()
+            if self.engine.comm_world > 1:  # sharded over the engine's communicator; the persistent mean stays replicated bit for bit
+                hdist.plan_mppi_sharded(self.engine, pop, H, A, self.refinements, self.gamma, self.beta, self.mean, self.lower_bound,
+                                        self.upper_bound, obj_fun.obs, fused.num_particles, seed=seed, plan_id=self.calls,
+                                        group=self.engine.comm_group)
+                return self.mean.clone()
             self.engine.plan_mppi(pop, H, A, self.refinements, self.gamma, self.beta, self.mean, self.lower_bound, self.upper_bound,
                                   obj_fun.obs, fused.num_particles, seed=seed, plan_id=self.calls)
             return self.mean.clone()
@@ -787,8 +807,12 @@ class ICEMOptimizer(Optimizer):
                            colored_noise_exponent=float(self.colored_noise_exponent))
             has_elite = self.elite is not None
             elite = self.elite.contiguous() if has_elite else torch.empty((K, H, A), device=self.device, dtype=torch.float32)
-            out = eng.plan_icem(p, x0, self.lower_bound, self.upper_bound, elite, has_elite, obj_fun.obs, fused.num_particles,
-                                seed=seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"))
+            if eng.comm_world > 1:  # sharded over the engine's communicator; the persistent elites stay replicated bit for bit
+                out = hdist.plan_icem_sharded(eng, p, x0, self.lower_bound, self.upper_bound, elite, has_elite, obj_fun.obs, fused.num_particles,
+                                              seed=seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"), group=eng.comm_group)[0]
+            else:
+                out = eng.plan_icem(p, x0, self.lower_bound, self.upper_bound, elite, has_elite, obj_fun.obs, fused.num_particles,
+                                    seed=seed, plan_id=self.calls, keep_idx=kwargs.get("keep_idx"))
             if self.num_iterations > 0:
                 self.elite = elite
             return out
@@ -841,7 +865,8 @@ class ICEMOptimizer(Optimizer):
                 values = values.to(device=self.device, dtype=torch.float32).contiguous()
             p = Engine.cem_params(population.shape[0], H, A, self.num_iterations, K, self.alpha, self.return_mean_elites,
                                   clipped_normal=False, unbiased_var=False)  # biased variance (:479)
-            eng.cem_refit(p, values, population, mu, var, best_value, best_solution, elite_idx)
+            elites = _reference_elites(values, K, self.device) if (self.sampler == "torch" and inject is None) else None
+            eng.cem_refit(p, values, population, mu, var, best_value, best_solution, elite_idx, elites=elites)
             new_elite = torch.empty((K, H, A), device=self.device, dtype=torch.float32)
             eng.gather_rows(population, elite_idx, new_elite)  # self.elite = population[elite_idx] (:476)
             self.elite = new_elite
@@ -926,9 +951,16 @@ class _OptimizerSnapshot:
                 self.engines.append(eng)
 
     def engines_report_timeout(self) -> bool:
+        """Did a persistent DEVICE-mode rollout of the plan give up on THIS rank -- or, when the ranks plan in lockstep, on ANY rank?
+        With a ``dist.ShardedEvalFn`` objective every iteration is a host-side collective all ranks must take part in: a rank that
+        re-ran its plan alone would issue a second series of all-gathers its peers never match.  The flag is therefore all-reduced
+        over the objective's group first, and the plan is re-run on every rank or on none.  (The fused sharded plans agree inside
+        ``hipets.dist.run_sharded`` and have consumed the flag by the time this is asked.)"""
         hit = False
         for eng in self.engines:
             hit = eng.check_async_error() or hit
+        if isinstance(self.eval_fn, hdist.ShardedEvalFn) and hdist.is_distributed():
+            hit = bool(hdist._worst_status(int(hit), self.eval_fn.group))
         return hit
 
     def restore(self):
@@ -957,6 +989,8 @@ class TrajectoryOptimizer:
 
     def optimize(self, trajectory_eval_fn: Callable[[torch.Tensor], torch.Tensor],
                  callback: Optional[Callable] = None) -> np.ndarray:
+        """(A plan that is re-run after a timed-out rollout -- see below -- invokes ``callback`` again for every iteration of the
+        second run: a callback that accumulates sees the iterations of the voided attempt followed by those of the valid one.)"""
         snapshot = _OptimizerSnapshot(self.optimizer, trajectory_eval_fn)
         best_solution = self.optimizer.optimize(trajectory_eval_fn, x0=self.previous_solution, callback=callback)
         plan = best_solution.cpu().numpy()  # the one device->host sync of a plan (:568)

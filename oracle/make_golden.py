@@ -317,6 +317,18 @@ FULL_CASES = {
     # BASELINE.json configs[3] taken literally: Gymnasium Humanoid-v4 (obs 376, 752 output columns) instead of the truncated-obs variant
     "cfg4p_icem": dict(obs=376, act=17, mkw=dict(ensemble_size=7, hid=200, seed=33, elite=[0, 1, 2, 3, 4], termination="humanoid"),
                        pop=1000, P=20, H=40, iters=5, optimizer="icem", module=7),
+    # The workloads the reference SHIPS (what `python -m mbrl.examples.main algorithm=pets overrides=...` plans with):
+    # conf/overrides/pets_halfcheetah.yaml:1-24 + conf/dynamics_model/gaussian_mlp_ensemble.yaml:4-13 + conf/algorithm/pets.yaml:20
+    # + util/env.py:79-82 + env/pets_halfcheetah.py:91-113: obs 18 through HalfCheetahEnv.preprocess_fn (18 model inputs + 6 actions),
+    # no_delta_list [0], 7 members of which 5 elites (a non-trivial subset), pop 400, elite ratio 0.16, alpha 0.12, P 20, H 30
+    "stock_halfcheetah": dict(obs=18, act=6, mkw=dict(ensemble_size=7, hid=200, seed=34, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah",
+                                                      no_delta_list=[0]),
+                              pop=400, P=20, H=30, iters=5, optimizer="cem", elite_ratio=0.16, alpha=0.12),
+    # conf/overrides/pets_cartpole.yaml:1-21 + util/env.py:71-74: cartpole_continuous (obs 4, act 1) with its reward / termination
+    # functions, 7 members / 5 elites, pop 350, elite ratio 0.1, alpha 0.1, P 20, H 15
+    "stock_cartpole": dict(obs=4, act=1, mkw=dict(ensemble_size=7, hid=200, seed=35, elite=[1, 2, 4, 5, 6], reward="cartpole",
+                                                  termination="cartpole"),
+                           pop=350, P=20, H=15, iters=5, optimizer="cem", elite_ratio=0.1, alpha=0.1),
 }
 
 
@@ -334,8 +346,8 @@ def full_case_agent_cfg(c, target_prefix, device, **extra):
         cfg = dict(_target_=f"{target_prefix}.MPPIOptimizer", num_iterations=c["iters"], population_size=c["pop"], gamma=0.9,
                    sigma=1.0, beta=0.9, device=device, lower_bound="???", upper_bound="???")
     else:
-        cfg = dict(_target_=f"{target_prefix}.CEMOptimizer", num_iterations=c["iters"], elite_ratio=0.1, population_size=c["pop"],
-                   alpha=0.1, device=device, lower_bound="???", upper_bound="???", return_mean_elites=True, clipped_normal=False)
+        cfg = dict(_target_=f"{target_prefix}.CEMOptimizer", num_iterations=c["iters"], elite_ratio=c.get("elite_ratio", 0.1),
+                   population_size=c["pop"], alpha=c.get("alpha", 0.1), device=device, lower_bound="???", upper_bound="???", return_mean_elites=True, clipped_normal=False)
     cfg.update(extra)
     return cfg
 

@@ -37,3 +37,15 @@ def engine():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return hipets.get_engine("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the oracle memo's new entries (tests/oracle_cache.py) where HIPETS_ORACLE_CACHE_OUT says, and report its hit rate."""
+    try:
+        import oracle_cache
+
+        oracle_cache.flush_all()
+        if oracle_cache.stats["hits"] or oracle_cache.stats["misses"]:
+            print(f"\n[oracle_cache] hits {oracle_cache.stats['hits']}, misses {oracle_cache.stats['misses']}")
+    except Exception as exc:  # never fail a run over the memo
+        print(f"[oracle_cache] {exc}")

@@ -1,0 +1,87 @@
+"""Memo of the ORACLE's outputs for the full-size GPU parity tests (test infrastructure).
+
+The replays of tests/test_gpu_plans_full_size.py and the BASELINE-size cases of tests/test_gpu_rollout.py feed the engine's own
+exported randomness (permutations / member schedules, eps, sampler noise: all counter-based, i.e. functions of seeds) and its
+recorded populations to `oracle.pets_oracle.rollout` -- 10^5 .. 10^7 candidate-steps of torch-CPU work per call, 139 CPU-minutes
+per run of the suite in round 3 (GPUTEST_r03: 633 s of the driver's 1 200 s).  The oracle is a pure function of its inputs, so its
+output is stored under a digest of the EXACT input bytes (model seed and kwargs, s0, the population, every injected draw):
+
+    tests/golden/oracle_cache/<group>.npz      key = blake2b of the inputs, value = the oracle's returns
+
+A hit returns what the oracle returned for precisely these inputs on the machine that recorded the entry (the build container's
+CPU; oracle == reference bitwise there: tests/test_oracle_vs_reference.py); a miss -- a kernel change that moves a population by
+one ulp, a new case -- computes the oracle as before and, when HIPETS_ORACLE_CACHE_OUT names a directory, writes the merged file
+there for committing (profiles/session_*.sh copy it from gpurun_out/).  HIPETS_ORACLE_CACHE=0 ignores the stored entries.
+Nothing here touches the product: the comparison the tests make is unchanged."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_cache")
+_groups = {}
+stats = {"hits": 0, "misses": 0}
+
+
+def _digest(parts) -> str:
+    h = hashlib.blake2b(digest_size=16)
+    for p in parts:
+        if p is None:
+            h.update(b"<none>")
+        elif isinstance(p, torch.Tensor):
+            a = p.detach().cpu().contiguous().numpy()
+            h.update(str((a.dtype, a.shape)).encode())
+            h.update(memoryview(a).cast("B"))
+        elif isinstance(p, np.ndarray):
+            a = np.ascontiguousarray(p)
+            h.update(str((a.dtype, a.shape)).encode())
+            h.update(memoryview(a).cast("B"))
+        else:
+            h.update(repr(p).encode())
+    return h.hexdigest()
+
+
+class _Group:
+    def __init__(self, name):
+        self.name, self.path = name, os.path.join(_DIR, name + ".npz")
+        self.data, self.dirty = {}, False
+        if os.environ.get("HIPETS_ORACLE_CACHE", "1") != "0" and os.path.exists(self.path):
+            with np.load(self.path) as z:
+                self.data = {k: z[k] for k in z.files}
+
+    def flush(self):
+        out = os.environ.get("HIPETS_ORACLE_CACHE_OUT")
+        if self.dirty and out:
+            os.makedirs(out, exist_ok=True)
+            np.savez_compressed(os.path.join(out, self.name + ".npz"), **self.data)
+            self.dirty = False
+
+
+def cached(group: str, inputs, compute):
+    """`compute()` (an oracle call) memoised under the digest of `inputs` (tensors, arrays, plain values) in file `group`."""
+    g = _groups.get(group)
+    if g is None:
+        g = _groups[group] = _Group(group)
+    key = _digest(inputs)
+    if key in g.data:
+        stats["hits"] += 1
+        return torch.from_numpy(g.data[key].copy())
+    stats["misses"] += 1
+    out = compute()
+    g.data[key] = out.detach().cpu().numpy()
+    g.dirty = True
+    g.flush()
+    return out
+
+
+def model_parts(om):
+    """Everything of an OracleModel the oracle's rollout reads (weights included: ~10 ms of hashing for the widest model)."""
+    return (list(om.weights) + list(om.biases) + [om.min_logvar, om.max_logvar, om.norm_mean, om.norm_std] +
+            [("fields", om.elite_models, om.activation, om.propagation, om.deterministic, om.target_is_delta, list(om.no_delta_list),
+              om.learned_rewards, om.obs_process, om.reward, om.termination, om.ensemble_kind)])
+
+
+def flush_all():
+    for g in _groups.values():
+        g.flush()

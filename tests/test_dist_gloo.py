@@ -77,11 +77,11 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
         comm_world, comm_rank = 2, 1
         destroyed = False
 
-        def __init__(self, message):
-            self.message = message
+        def __init__(self, message, kind=hipets.ERR_RUNTIME):
+            self.message, self.kind = message, kind
 
         def plan_cem_sharded(self, *a, **k):
-            raise hipets.HipetsError(self.message)
+            raise hipets.HipetsError(self.message, self.kind)
 
         def plan_cem(self, params, x0, lower, upper, s0, P, seed=0, plan_id=0):
             return ("single-gpu plan", seed, plan_id)
@@ -103,7 +103,13 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
     plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=3, plan_id=10)  # no communicator any more
     assert plan[0] == "single-gpu plan" and fell_back
     with pytest.raises(hipets.HipetsError, match="act_dim"):
-        hdist.plan_cem_sharded(FakeEngine("act_dim 5 != model act_dim 6"), None, None, None, None, None, 20)
+        hdist.plan_cem_sharded(FakeEngine("act_dim 5 != model act_dim 6", hipets.ERR_INVALID_ARGUMENT), None, None, None, None, None, 20)
+    # the CLASS of the error decides (hipets_last_error_kind), not its wording: the time-out report an earlier unasked launch leaves
+    # contains none of "RCCL / failed: / hipMalloc" and is a runtime failure all the same (round-3 advice)
+    eng = FakeEngine("a persistent DEVICE-mode rollout timed out waiting for rows of another workgroup ... nobody asked", hipets.ERR_TIMEOUT)
+    with pytest.warns(UserWarning, match="falling back to a single-GPU plan"):
+        plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=4, plan_id=1)
+    assert plan == ("single-gpu plan", 4, 1) and fell_back and eng.destroyed
 
     class TimedOutEngine(FakeEngine):  # the plan was enqueued and "ran", but a persistent rollout inside it gave up
         def plan_cem_sharded(self, *a, **k):
@@ -116,3 +122,104 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
     with pytest.warns(UserWarning, match="timed out"):
         plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=1, plan_id=2)
     assert plan == ("single-gpu plan", 1, 2) and fell_back and eng.destroyed
+
+
+def test_failed_sharded_mppi_and_icem_attempts_are_undone_before_the_single_gpu_plan():
+    """MPPI's persistent mean and iCEM's persistent elites are modified IN PLACE by a plan (trajectory_opt.py:238-311 self.mean,
+    :476 self.elite): when the sharded attempt fails half way, the single-GPU fallback must start from what they were."""
+    import hipets
+    from hipets import dist as hdist
+
+    class Eng:
+        comm_world, comm_rank, comm_group = 2, 0, None
+        seen = None
+
+        def synchronize(self):
+            pass
+
+        def check_async_error(self):
+            return False
+
+        def comm_destroy(self):
+            self.comm_world = 1
+
+        def plan_mppi_sharded(self, pop, H, A, it, gamma, beta, mean, *a, **k):
+            mean += 7.0  # half-way state of a plan that then dies in a collective
+            raise hipets.HipetsError("RCCL error 2", hipets.ERR_RUNTIME)
+
+        def plan_mppi(self, pop, H, A, it, gamma, beta, mean, *a, **k):
+            self.seen = mean.clone()
+            mean += 1.0
+            return mean
+
+        def plan_icem_sharded(self, p, x0, lo, up, elite, has_elite, *a, **k):
+            elite.fill_(-3.0)
+            raise hipets.HipetsError("hipMalloc(123) failed", hipets.ERR_RUNTIME)
+
+        def plan_icem(self, p, x0, lo, up, elite, has_elite, *a, **k):
+            self.seen = elite.clone()
+            return "icem plan"
+
+    eng, mean = Eng(), torch.full((3, 2), 0.5)
+    with pytest.warns(UserWarning, match="falling back"):
+        out, fell_back = hdist.plan_mppi_sharded(eng, 10, 3, 2, 2, 0.9, 0.9, mean, None, None, None, 5)
+    assert fell_back and torch.equal(eng.seen, torch.full((3, 2), 0.5)) and torch.equal(mean, torch.full((3, 2), 1.5)) and out is mean
+    eng, elite = Eng(), torch.arange(12.0).reshape(2, 3, 2)
+    with pytest.warns(UserWarning, match="falling back"):
+        out, fell_back = hdist.plan_icem_sharded(eng, None, None, None, None, elite, True, None, 5)
+    assert fell_back and out == "icem plan" and torch.equal(eng.seen, torch.arange(12.0).reshape(2, 3, 2))
+
+
+def _timeout_worker(rank, world, port, tmpdir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "mbrl-lib_amd"))
+    from hipets import dist as hdist
+    from hipets.engine import Engine
+    from hipets.planning import _BoundObjective, _OptimizerSnapshot
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Eng(Engine):  # an engine whose time-out flag is scripted (no GPU here)
+            def __init__(self, hits):
+                self.hits = list(hits)
+
+            def check_async_error(self):
+                return self.hits.pop(0) if self.hits else False
+
+        class Inner:
+            calls = 0
+
+            def __init__(self, eng):
+                self.engine = eng
+
+            def __call__(self, s0, a):
+                return a.sum(dim=(1, 2))
+
+        class Opt:
+            calls = 3
+
+        # plan 1: only rank 1's engine reports a timed-out rollout; plan 2: nobody does
+        eng = Eng([rank == 1, False])
+        obj = _BoundObjective(hdist.ShardedEvalFn(Inner(eng)), np.zeros(2, np.float32))
+        snap = _OptimizerSnapshot(Opt(), obj)
+        first = snap.engines_report_timeout()   # must be True on BOTH ranks: re-run everywhere or nowhere
+        second = snap.engines_report_timeout()
+        # an objective that is not sharded never starts a collective (independent agents per rank must not be coupled)
+        lone = _OptimizerSnapshot(Opt(), _BoundObjective(Inner(Eng([rank == 0])), np.zeros(2, np.float32))).engines_report_timeout()
+        torch.save((first, second, lone), os.path.join(tmpdir, f"t{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_timed_out_plan_is_rerun_on_every_rank_or_none_world2_gloo(tmp_path):
+    """Round-3 advice: TrajectoryOptimizer.optimize re-runs a plan whose rollouts timed out; with a ShardedEvalFn objective a
+    rank re-running alone would issue all-gathers its peers never match.  The flag is all-reduced over the objective's group."""
+    world = 2
+    mp.spawn(_timeout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
+    assert r0[:2] == (True, False) and r1[:2] == (True, False)
+    assert r0[2] is True and r1[2] is False  # purely local

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import hipets
+import oracle_cache as oc
 from conftest import to_spec
 from oracle import feistel_perm as fp
 from oracle import pets_oracle as po
@@ -39,8 +40,9 @@ def test_device_mode_replayed_through_oracle(engine, case):
     if om.propagation != "expectation":
         perms = engine.device_perms(H, pop * P, seed, sid).cpu()
         assert tuple(perms.shape) == ((pop * P,) if om.propagation == "fixed_model" else (H, pop * P))
-    eps = None if om.deterministic else engine.fast_normals(H, pop * P, seed, sid).cpu()
-    ref = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    # (eps = the library's Philox normals of (seed, stream), exported only when the oracle has to run: tests/oracle_cache.py)
+    ref = oc.cached("rollout_sizes", ["device", *oc.model_parts(om), actions, s0, P, perms, ("philox", seed, sid)],
+                    lambda: po.rollout(om, actions, s0, P, perms=perms, eps=None if om.deterministic else engine.fast_normals(H, pop * P, seed, sid).cpu()))
     assert_returns_close(out, ref)
     # determinism and seed sensitivity
     again = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid)

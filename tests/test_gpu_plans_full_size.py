@@ -15,6 +15,7 @@ import pytest
 import torch
 
 import hipets
+import oracle_cache as oc
 from conftest import to_spec
 from hipets.planning import _BoundObjective
 from oracle import pets_oracle as po
@@ -36,17 +37,28 @@ def make_case(name):
 
 def replay_rollout(engine, om, s0, P, H, mode, seed):
     """objective(population, stream) through the oracle with the engine's exported randomness of (seed, stream)."""
+    parts = oc.model_parts(om)
+
     def f(population, stream):
         pop = population.shape[0]
         B = pop * P
-        eps = engine.fast_normals(H, B, seed, stream).cpu()
-        if mode == "device":
-            return po.rollout(om, population, s0, P, perms=engine.device_perms(H, B, seed, stream).cpu(), eps=eps)
-        nwg, r = engine.fast_geometry(pop, P, H)
-        sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
-        rows = torch.arange(B)
-        wg = ((rows // P) // (16 * r)) * P + rows % P
-        return po.rollout(om, population, s0, P, members=torch.stack([sched[t][wg].long() for t in range(H)]), eps=eps)
+
+        def run():
+            eps = engine.fast_normals(H, B, seed, stream).cpu()
+            if mode == "device":
+                return po.rollout(om, population, s0, P, perms=engine.device_perms(H, B, seed, stream).cpu(), eps=eps)
+            return po.rollout(om, population, s0, P, members=torch.stack([sched[t][wg].long() for t in range(H)]), eps=eps)
+
+        geometry = ()
+        if mode != "device":
+            nwg, r = engine.fast_geometry(pop, P, H)
+            sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
+            rows = torch.arange(B)
+            wg = ((rows // P) // (16 * r)) * P + rows % P
+            geometry = (nwg, r, sched)
+        # the draws are functions of (seed, stream) -- counter-based; the population is what the engine recorded: the oracle's answer
+        # for exactly these bytes is memoised (tests/oracle_cache.py); a kernel change that moves a population by one ulp recomputes
+        return oc.cached("plans_full_size", [mode, *parts, s0, P, H, ("counters", seed, stream), *geometry, population], run)
 
     return f
 
@@ -70,12 +82,17 @@ def elites_agree(dev_idx, ref_values, K):
 
 
 @pytest.mark.parametrize("mode", ["device", "fast"])
-def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode):
-    c, om, s0 = make_case("cfg2_cem")
+@pytest.mark.parametrize("case_name", ["cfg2_cem", "stock_halfcheetah", "stock_cartpole"])
+def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode, case_name):
+    """cfg2_cem = BASELINE.json configs[1]; stock_halfcheetah / stock_cartpole = the workloads the reference ships
+    (conf/overrides/pets_halfcheetah.yaml, pets_cartpole.yaml: obs preprocessing + no_delta_list + 7 members / 5 elites, their own
+    population sizes, elite ratios and alphas)."""
+    c, om, s0 = make_case(case_name)
     obs, act, P, H, pop, iters = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"]
+    ratio, alpha = c.get("elite_ratio", 0.1), c.get("alpha", 0.1)
     fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=5, mode=mode)
     lower, upper = -torch.ones(H, act), torch.ones(H, act)
-    opt = hipets.CEMOptimizer(iters, 0.1, pop, lower.tolist(), upper.tolist(), 0.1, DEV, return_mean_elites=True, seed=9)
+    opt = hipets.CEMOptimizer(iters, ratio, pop, lower.tolist(), upper.tolist(), alpha, DEV, return_mean_elites=True, seed=9)
     K = int(opt.elite_num)
     x0 = torch.zeros(H, act)
     for call in range(2):  # the second plan starts from the shifted first plan, like consecutive act() calls
@@ -84,7 +101,7 @@ def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode):
         torch.cuda.synchronize()
         engine.set_plan_trace(0)
         seed, plan_id = opt.seed ^ fn.seed, opt.calls
-        p = engine.cem_params(pop, H, act, iters, K, 0.1, True, False)
+        p = engine.cem_params(pop, H, act, iters, K, alpha, True, False)
         one, zero = torch.ones(H, act, device=DEV), torch.zeros(H, act, device=DEV)
         z = []
         for i in range(iters):  # the sampler on a unit problem returns its own truncated normals
@@ -102,12 +119,14 @@ def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode):
 
         teacher = [(tr["mus"][i].cpu(), tr["dispersions"][i].cpu()) for i in range(iters)]
         rec = []
-        po.cem_optimize(obj, x0, lower, upper, iters, 0.1, pop, 0.1, return_mean_elites=True, noise=z, record=rec, teacher=teacher)
+        po.cem_optimize(obj, x0, lower, upper, iters, ratio, pop, alpha, return_mean_elites=True, noise=z, record=rec, teacher=teacher)
         for i in range(iters):
             assert torch.allclose(tr["populations"][i].cpu(), rec[i]["population"], rtol=0, atol=1e-5), (call, i)
             check_values(tr["values"][i].cpu(), rec[i]["values"])
             if elites_agree(tr["elite_idx"][i].cpu(), rec[i]["values"], K):
-                assert int(tr["elite_idx"][i][0]) == int(rec[i]["elite_idx"][0])
+                # the best candidate: the same one, or one that ties with it (0 / 1 rewards tie many candidates at the top)
+                top_dev, top_ref = int(tr["elite_idx"][i][0]), int(rec[i]["elite_idx"][0])
+                assert top_dev == top_ref or abs(float(rec[i]["values"][top_dev] - rec[i]["values"][top_ref])) <= 1e-4
                 assert torch.allclose(tr["mus"][i].cpu(), rec[i]["mu"], rtol=0, atol=1e-4), (call, i)  # T4
                 assert torch.allclose(tr["dispersions"][i].cpu(), rec[i]["disp"], rtol=1e-4, atol=1e-5), (call, i)
         assert torch.equal(out, tr["mus"][iters - 1])

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import oracle_cache as oc
 from conftest import GOLDEN, to_spec
 from oracle import pets_oracle as po
 from oracle.golden_io import load_case
@@ -81,6 +82,15 @@ SIZES = [
     # cfg4' (BASELINE configs[3] literally: Humanoid-v4, obs 376 -> 752 output columns, 7 members / 5 elites) at a multi-turn size:
     # 4 200 rows = 840 per member = 53 one-tile workgroups per member, 265 logical workgroups on 256 CUs
     (376, 17, 210, 20, 3, dict(ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")),
+    # The workloads the reference SHIPS, at full size (oracle/make_golden.py FULL_CASES stock_*):
+    # pets_halfcheetah (conf/overrides/pets_halfcheetah.yaml:1-24, env/pets_halfcheetah.py:91-113): obs 18 through preprocess_fn,
+    # no_delta_list [0], 7 members / 5 elites, pop 400 x 20 particles, H 30
+    (18, 6, 400, 20, 30, dict(ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0])),
+    # pets_cartpole (conf/overrides/pets_cartpole.yaml:1-21, util/env.py:71-74): pop 350 x 20 particles, H 15, 7 members / 5 elites
+    (4, 1, 350, 20, 15, dict(ensemble_size=7, hid=200, elite=[1, 2, 4, 5, 6], reward="cartpole", termination="cartpole")),
+    # the other PETS obs preprocessor (env/pets_cartpole.py:78-101: [sin s1, cos s1, s0, s2:], one input column more than obs dims) with
+    # its reward function, in-kernel randomness
+    (4, 1, 80, 5, 6, dict(ensemble_size=5, hid=200, obs_process="cartpole_pets", reward="cartpole_pets")),
 ]
 # in-kernel randomness replays (FAST / DEVICE): everything but the expectation-propagation f32-normaliser case in FAST
 FAST_SIZES = SIZES[:9] + SIZES[10:]
@@ -92,7 +102,8 @@ def test_exact_mode_matches_oracle(engine, case):
     obs, act, pop, P, H, mkw = case
     om, actions, s0, perms, eps = _random_case(obs, act, pop, P, H, **mkw)
     engine.set_model(to_spec(om, obs, act))
-    ref = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    # (every input derives from seeds on the CPU: the oracle's answer is memoised under their digest, tests/oracle_cache.py)
+    ref = oc.cached("rollout_sizes", ["exact", *oc.model_parts(om), actions, s0, P, perms, eps], lambda: po.rollout(om, actions, s0, P, perms=perms, eps=eps))
     out = engine.rollout(actions.to(DEV), s0, P, mode="exact", perms=None if perms is None else perms.to(DEV),
                          eps=None if eps is None else eps.to(DEV))
     assert_returns_close(out, ref)
@@ -109,11 +120,12 @@ def test_fast_mode_replayed_through_oracle(engine, case):
     nwg, r = engine.fast_geometry(pop, P, H)
     out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
-    eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
     rows = torch.arange(pop * P)
     wg = ((rows // P) // (16 * r)) * P + rows % P
     members = torch.stack([sched[0 if om.propagation == "fixed_model" else t][wg].long() for t in range(H)])
-    ref = po.rollout(om, actions, s0, P, members=members, eps=eps)
+    # eps = the library's Philox normals of (seed, stream): a function of the counters, exported only when the oracle has to run
+    ref = oc.cached("rollout_sizes", ["fast", *oc.model_parts(om), actions, s0, P, members, ("philox", seed, sid)],
+                    lambda: po.rollout(om, actions, s0, P, members=members, eps=engine.fast_normals(H, pop * P, seed, sid).cpu()))
     assert_returns_close(out, ref)
     # the schedule is balanced: every member slot gets floor/ceil(nwg / M) workgroups at every step
     M = len(om.active_members)
@@ -390,8 +402,36 @@ def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case
     engine.set_model(to_spec(om, obs, act))
     a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3)
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=True)
-    assert torch.equal(a, b)
+    c = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=2)  # the hidden-static instance
+    assert torch.equal(a, b) and torch.equal(a, c)
     assert torch.isfinite(a).all()
+
+
+# every model of the reference's default hidden width (200) that has no shape-specialised instance: the workloads the reference
+# ships (obs preprocessing, other reward / termination functions), propagation methods, normalisers, learned rewards
+HID200_CASES = [SIZES[12], SIZES[13], SIZES[14],
+                (11, 3, 60, 5, 6, dict(ensemble_size=5, hid=200, termination="hopper", normalizer="f32")),
+                (17, 6, 40, 6, 5, dict(ensemble_size=3, hid=200, propagation="fixed_model", learned_rewards=True, reward=None)),
+                (23, 7, 25, 4, 4, dict(ensemble_size=4, hid=208, reward="pusher", propagation="expectation")),
+                (6, 2, 33, 5, 5, dict(ensemble_size=5, hid=193, deterministic=True, normalizer="none"))]
+
+
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("rows_per_group", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("case", HID200_CASES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_hidden_static_instances_equal_the_generic_kernel_bitwise(engine, case, mode, rows_per_group):
+    """Models whose hidden layers have 13 column tiles (hid 193..208: the reference's default 200) run an instance of the rollout
+    kernel with the hidden layers' shape as a compile-time fact and everything else -- obs preprocessing, reward / termination
+    functions, normaliser, output width, propagation -- decided at run time (KSpec::HID_STATIC).  Same arithmetic as the fully
+    generic instance: same bits, for every row-tile count."""
+    obs, act, pop, P, H, mkw = case
+    if rows_per_group and pop * P * H > 100000 and rows_per_group != 2:
+        pytest.skip("full-size cases: the default geometry and one forced one")
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
+    b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])

@@ -34,7 +34,8 @@ def oracle_agent(name, meta):
     def act_fn(observation):
         obj = lambda pop_: po.rollout(om, pop_, observation, P, global_rng=True, generator=gen)  # noqa: E731
         if c["optimizer"] == "cem":
-            opt = lambda x0: po.cem_optimize(obj, x0, st.lower, st.upper, c["iters"], 0.1, c["pop"], 0.1, return_mean_elites=True)  # noqa: E731
+            opt = lambda x0: po.cem_optimize(obj, x0, st.lower, st.upper, c["iters"], c.get("elite_ratio", 0.1), c["pop"], c.get("alpha", 0.1),  # noqa: E731
+                                             return_mean_elites=True)  # noqa: E731
         elif c["optimizer"] == "mppi":
             opt = lambda x0: po.mppi_optimize(obj, mppi, st.lower, st.upper, c["iters"], c["pop"], 0.9, 1.0, 0.9)  # noqa: E731
         else:
