@@ -152,11 +152,13 @@ int launch_rollout(hipets_engine* e, int R, int grid, size_t lds, const RolloutA
         }
     }
     hipError_t err;
+    RolloutArgs rl = ra;
+    rl.lds_bytes = (unsigned)lds;  // (debug builds check every LDS section against it)
     switch (R) {
-        case 1: err = launch_rollout_r1(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
-        case 2: err = launch_rollout_r2(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
-        case 3: err = launch_rollout_r3(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
-        case 4: err = launch_rollout_r4(grid, (unsigned)lds, (int)e->lds_max, e->md, ra, st, a, b); break;
+        case 1: err = launch_rollout_r1(grid, (unsigned)lds, (int)e->lds_max, e->md, rl, st, a, b); break;
+        case 2: err = launch_rollout_r2(grid, (unsigned)lds, (int)e->lds_max, e->md, rl, st, a, b); break;
+        case 3: err = launch_rollout_r3(grid, (unsigned)lds, (int)e->lds_max, e->md, rl, st, a, b); break;
+        case 4: err = launch_rollout_r4(grid, (unsigned)lds, (int)e->lds_max, e->md, rl, st, a, b); break;
         default: return fail("unsupported rows_per_group %d (1..%d)", R, kMaxR);
     }
     if (timed) e->events.emplace_back(a, b);  // recorded (or leaked to the pool) either way
@@ -255,7 +257,8 @@ struct StreamScope {
     hipets_engine* e;
     hipStream_t st;
     ~StreamScope() {
-        if (e && e->last_done) (void)hipEventRecord(e->last_done, st);
+        static const bool off = std::getenv("HIPETS_NO_STREAM_SCOPE") != nullptr;  // (A/B measurements only)
+        if (e && e->last_done && !off) (void)hipEventRecord(e->last_done, st);
     }
 };
 #define ENTER_STREAM(e, st)                \

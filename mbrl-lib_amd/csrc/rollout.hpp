@@ -127,6 +127,7 @@ struct RolloutArgs {
                                    // set every later poll of the launch gives up after <= 64 spins, so a stranded grid drains in
                                    // milliseconds instead of waiting out the bound at every step and turn
     long long poll_ticks;          // bound of one hand-over poll in 100 MHz wall-clock ticks (hipets_set_handover_timeout; default 0.2 s)
+    unsigned lds_bytes;            // the dynamic LDS size the launch was given (debug builds check every LDS section against it: HIPETS_DEBUG_BOUNDS)
     int* census;                   // DEVICE [2], launcher only: when set the launch is the co-residency SELF-TEST of this kernel instance at
                                    // this grid, not a rollout -- every workgroup arrives at census[0] and waits (bounded by poll_ticks)
                                    // until all gridDim.x have; those that saw everybody count themselves in census[1]
@@ -238,6 +239,28 @@ __device__ __forceinline__ void prefetch_issue(const NextOp& n, const int lane, 
 #define HIPETS_MINWAVES_R2 2
 #endif
 template <int R> struct MinWavesOf { static constexpr int value = R == 1 ? HIPETS_MINWAVES_R1 : (R == 2 ? HIPETS_MINWAVES_R2 : 1); };
+
+// Debug build (__graft_entry__.build_debug: -O1 -g -DHIPETS_DEBUG_BOUNDS=1, host side under AddressSanitizer): every LDS section of
+// the rollout kernel is checked against the dynamic LDS size of the launch, and the indexed LDS accesses of the elementwise phases
+// against their section.  A violated bound aborts the kernel (device assert -> the next HIP call reports it).  Off in the shipped
+// library: the checks cost registers in kernels that sit at the limit.
+#ifndef HIPETS_DEBUG_BOUNDS
+#define HIPETS_DEBUG_BOUNDS 0
+#endif
+#if HIPETS_DEBUG_BOUNDS
+// (not <cassert>'s assert: the generic lambdas of wave_gemm are implicitly __host__ __device__, where the host's __assert_fail is not callable)
+__host__ __device__ inline void hipets_bound_fail(const int line) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    printf("hipets: bound violated at rollout.hpp:%d (workgroup %d, thread %d)\n", line, (int)blockIdx.x, (int)threadIdx.x);
+    __builtin_trap();
+#else
+    (void)line;
+#endif
+}
+#define HIPETS_BOUND(cond) do { if (!(cond)) hipets_bound_fail(__LINE__); } while (0)
+#else
+#define HIPETS_BOUND(cond) ((void)0)
+#endif
 
 struct NoTail {};  // wave_gemm's TL: the ordinary epilogue (activation, store as the next op's LDS image)
 // A fused tail = three stages over the accumulators (units) a wave finished: prep(slot, c, r) for EVERY unit first -- it only
@@ -681,6 +704,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     // a wave's VALU work is not hidden behind anything here, so the instruction count is the cost)
     auto store = [&](auto actfn) __attribute__((always_inline)) {
         const int j = lane & 15, g4 = 4 * (lane >> 4);
+        HIPETS_BOUND(c_first >= 0 && (CT == 0 || (c_first + kWaves * (CT - 1)) * 16 + g4 + 3 < ld) && KC >= 1 && KC * 16 <= ldi);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int col = (c_first + kWaves * ct) * 16 + g4;
@@ -1423,6 +1447,22 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.expacc = reinterpret_cast<float*>(p);
+#if HIPETS_DEBUG_BOUNDS
+        {   // every section starts inside the launch's dynamic LDS, 16-byte aligned, in layout order; the last one ends inside it
+            const char* const secs[] = {(char*)sm.buf0, (char*)sm.buf1, (char*)sm.tot, (char*)sm.lrew, (char*)sm.term, (char*)sm.rowid, (char*)sm.pend,
+                                        (char*)sm.lmeta, (char*)sm.prof, (char*)sm.dump, (char*)sm.state, (char*)sm.actn, (char*)sm.nmean, (char*)sm.nstd,
+                                        (char*)sm.minlv, (char*)sm.maxlv, (char*)sm.nodelta, (char*)sm.sched, (char*)sm.expacc};
+            constexpr int kSecs = (int)(sizeof(secs) / sizeof(secs[0]));
+            for (int i = 0; i < kSecs; ++i) {
+                HIPETS_BOUND(secs[i] >= smem && secs[i] <= smem + ra.lds_bytes);
+                HIPETS_BOUND(((size_t)(secs[i] - smem) & 15) == 0);
+                HIPETS_BOUND(i == 0 || secs[i] >= secs[i - 1]);
+            }
+            const bool expect = !S::LEAN && md.propagation == HIPETS_PROP_EXPECTATION;
+            HIPETS_BOUND((char*)sm.expacc + (expect ? align16((size_t)ROWS * md.out_total * 4) : 0) <= smem + ra.lds_bytes);
+            HIPETS_BOUND(md.Kp0 <= (kWide ? md.ld_in : ld_k) && md.obs_in + md.act_dim == md.in_dim && md.in_dim <= md.Kp0);
+        }
+#endif
     }
     const int tid = threadIdx.x;
     if (ra.census) {
@@ -1703,6 +1743,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 else if constexpr (NORM == HIPETS_NORM_F32) x = (x - (float)sm.nmean[cc]) / (float)sm.nstd[cc];
                 v[q] = (c < md.in_dim && valid) ? x : 0.f;
             }
+            HIPETS_BOUND(s >= 0 && s < ROWS && 4 * cq + 3 < ld_in);
             if constexpr (kB3) {  // three bf16 pieces per value, in the B-operand layout of wave_gemm_b3
                 u32x2 pc[3];
                 split3x4(f32x4{v[0], v[1], v[2], v[3]}, pc);
@@ -1874,6 +1915,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #pragma unroll
             for (int q = 0; q < kG; ++q)
                 if (gs[q] >= 0) {
+                    HIPETS_BOUND(gs[q] < ROWS && gv[q] >= 0 && gv[q] < NVP);
                     if (!soft[q]) {
                         using OM = ObsMap<S::OBSP>;
                         const int d = 2 * gv[q];
@@ -1982,6 +2024,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const int s = r * kTile + j;
                 const int d0 = 8 * c + 2 * g;
                 const int rid = q.rid;
+                HIPETS_BOUND(s >= 0 && s < ROWS && r >= 0 && r < R && c >= 0 && 16 * c < 2 * md.out_dim + 16 && rid < ra.B);
                 const bool okA = rid >= 0 && d0 < md.obs_dim, okB = rid >= 0 && d0 + 1 < md.obs_dim;
                 const float mxA = q.mxA, mxB = q.mxB, mnA = q.mnA, mnB = q.mnB, pA = q.pA, pB = q.pB;
                 const bool addA = md.target_is_delta && !q.ndA, addB = md.target_is_delta && !q.ndB;
@@ -2172,6 +2215,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 for (int item = tid; item < ROWS * nblk; item += kThreads) {
                     const int s = item / nblk, blk = item % nblk;
                     const int rid = sm.rowid[s];
+                    HIPETS_BOUND(s < ROWS && rid < ra.B && 4 * blk < md.out_dim + 4 && md.out_total <= ld_k);
                     if (rid < 0) continue;
                     float nrm[4] = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (MODE == 1) {
@@ -2376,6 +2420,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #pragma unroll
                 for (int q = 0; q < kGT; ++q)
                     if (gs[q] >= 0) {
+                        HIPETS_BOUND(gs[q] < ROWS && gv[q] >= 0 && gv[q] < NVP);
                         if (!soft[q]) {
                             const int d = 2 * gv[q];
                             const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
