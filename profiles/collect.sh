@@ -25,6 +25,13 @@ timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_
 for c in cfg1_cartpole cfg4_humanoid_truncated_obs cfg4_humanoid_v4_obs376 cfg5_cheetah_run planet cfg1_cem_plan cfg4_icem_plan cfg5_mppi_plan; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_$c -o t -- python profiles/other_configs.py --only $c --mode device --reps 5 > $OUT/cfg_$c.log 2>&1
 done
+# the workloads the reference ships (round 4): kernel trace of their rollouts, both randomness modes
+for W in stock_halfcheetah stock_cartpole; do
+  for MODE in device fast; do
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_${W}_$MODE -o t -- python profiles/stock_workloads.py --only $W --mode $MODE --reps 10 --no-plans > $OUT/cfg_${W}_$MODE.log 2>&1
+  done
+done
+python profiles/stock_workloads.py --sweep-r --generic > $OUT/stock_workloads.json 2> $OUT/stock_workloads.err
 # the separately reported bf16x3 arithmetic mode: kernel trace of cfg2 rollouts in both randomness modes, L2 hit / miss counters
 for MODE in device fast; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_cfg2_bf16x3_$MODE -o t -- python profiles/precision_probe.py --precision bf16x3 --mode $MODE --reps 10 > $OUT/cfg_cfg2_bf16x3_$MODE.log 2>&1

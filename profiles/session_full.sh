@@ -8,7 +8,7 @@ OUT=gpurun_out/full_$TAG
 mkdir -p $OUT
 run() { name=$1; shift; echo "== $name: $*" ; ( time timeout ${TMO:-1200} "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)"; }
 run smoke python -c "import __graft_entry__ as g; g.smoke()"
-run tests python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider
+HIPETS_ORACLE_CACHE_OUT=$PWD/gpurun_out/oracle_cache run tests python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider --durations=15
 run bench python bench.py
 grep -h '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json
 HIPETS_DIST_BACKEND=gloo run bench_gloo2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 2

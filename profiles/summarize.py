@@ -135,6 +135,14 @@ if tcc:
         per["l2_hit_frac"] = per.get("TCC_HIT_sum", 0.0) / (per.get("TCC_HIT_sum", 0.0) + per.get("TCC_MISS_sum", 1.0))
     json.dump({"workload": "cfg2 rollout, precision bf16x3, DEVICE mode (persistent form, XCD-major workgroup order)", "per_launch": per},
               open(os.path.join(dst, f"{tag}_bf16x3_l2.json"), "w"), indent=1)
+for w in ("stock_halfcheetah", "stock_cartpole"):  # the raw rocprofv3 statistics of the shipped workloads' rollouts, verbatim
+    for mode in ("device", "fast"):
+        st = sorted(glob.glob(os.path.join(src, f"cfg_{w}_{mode}", "**", "t_kernel_stats.csv"), recursive=True))
+        if st:
+            shutil.copy(st[0], os.path.join(dst, f"{tag}_{w}_kernel_stats_{mode}.csv"))
+sw = os.path.join(src, "stock_workloads.json")
+if os.path.exists(sw) and os.path.getsize(sw):
+    shutil.copy(sw, os.path.join(dst, f"{tag}_stock_workloads.json"))
 oc = os.path.join(src, "other_configs.json")
 if os.path.exists(oc) and os.path.getsize(oc):
     shutil.copy(oc, os.path.join(dst, f"{tag}_other_configs.json"))

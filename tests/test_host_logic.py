@@ -280,3 +280,63 @@ def test_reference_noise_consumes_the_global_generator_like_the_reference():
     c = _reference_noise((7, 2), clipped_normal=True)
     torch.manual_seed(5)
     assert torch.equal(c, torch.randn(7, 2))
+
+
+def test_oracle_memo_keys_on_the_exact_input_bytes(tmp_path, monkeypatch):
+    """tests/oracle_cache.py: a hit needs byte-identical inputs (one ulp in a population is a miss), misses are written where
+    HIPETS_ORACLE_CACHE_OUT says, HIPETS_ORACLE_CACHE=0 ignores stored entries."""
+    import importlib
+
+    import numpy as np
+    import torch
+
+    import oracle_cache as oc
+
+    oc = importlib.reload(oc)
+    monkeypatch.setattr(oc, "_DIR", str(tmp_path / "store"))
+    monkeypatch.setenv("HIPETS_ORACLE_CACHE_OUT", str(tmp_path / "store"))
+    calls = []
+
+    def compute(v):
+        def f():
+            calls.append(v)
+            return torch.full((3,), float(v))
+        return f
+
+    x = torch.linspace(0, 1, 8)
+    a = oc.cached("unit", ["fast", x, np.float32(0.5), ("philox", 1, 2)], compute(1))
+    b = oc.cached("unit", ["fast", x.clone(), np.float32(0.5), ("philox", 1, 2)], compute(2))  # same bytes: a hit, compute not called
+    assert torch.equal(a, b) and calls == [1]
+    y = x.clone()
+    y[3] = torch.nextafter(y[3], torch.tensor(2.0))  # one ulp
+    c = oc.cached("unit", ["fast", y, np.float32(0.5), ("philox", 1, 2)], compute(3))
+    d = oc.cached("unit", ["fast", x, np.float32(0.5), ("philox", 1, 3)], compute(4))  # another stream counter
+    assert calls == [1, 3, 4] and float(c[0]) == 3.0 and float(d[0]) == 4.0
+    assert (tmp_path / "store" / "unit.npz").exists()
+    oc2 = importlib.reload(oc)  # a fresh process: entries come back from the file
+    monkeypatch.setattr(oc2, "_DIR", str(tmp_path / "store"))
+    e = oc2.cached("unit", ["fast", x, np.float32(0.5), ("philox", 1, 2)], compute(5))
+    assert float(e[0]) == 1.0 and calls == [1, 3, 4] and oc2.stats["hits"] == 1
+    monkeypatch.setenv("HIPETS_ORACLE_CACHE", "0")
+    oc3 = importlib.reload(oc2)
+    monkeypatch.setattr(oc3, "_DIR", str(tmp_path / "store"))
+    f = oc3.cached("unit", ["fast", x, np.float32(0.5), ("philox", 1, 2)], compute(6))
+    assert float(f[0]) == 6.0
+
+
+def test_committed_oracle_memo_is_loadable_and_small():
+    import os
+
+    import numpy as np
+
+    from conftest import GOLDEN
+
+    d = os.path.join(GOLDEN, "oracle_cache")
+    files = [f for f in os.listdir(d) if f.endswith(".npz")]
+    assert files, "tests/golden/oracle_cache is empty: run the GPU suite with HIPETS_ORACLE_CACHE_OUT and commit its output"
+    total = 0
+    for f in files:
+        total += os.path.getsize(os.path.join(d, f))
+        with np.load(os.path.join(d, f)) as z:
+            assert len(z.files) > 0 and all(len(k) == 32 for k in z.files)  # blake2b-128 hex digests
+    assert total < 4 << 20
