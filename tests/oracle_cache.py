@@ -8,11 +8,14 @@ output is stored under a digest of the EXACT input bytes (model seed and kwargs,
 
     tests/golden/oracle_cache/<group>.npz      key = blake2b of the inputs, value = the oracle's returns
 
-A hit returns what the oracle returned for precisely these inputs on the machine that recorded the entry (the build container's
-CPU; oracle == reference bitwise there: tests/test_oracle_vs_reference.py); a miss -- a kernel change that moves a population by
-one ulp, a new case -- computes the oracle as before and, when HIPETS_ORACLE_CACHE_OUT names a directory, writes the merged file
-there for committing (profiles/session_*.sh copy it from gpurun_out/).  HIPETS_ORACLE_CACHE=0 ignores the stored entries.
-Nothing here touches the product: the comparison the tests make is unchanged."""
+A hit returns what the oracle returned for precisely these inputs on the machine that recorded the entry (the GPU box's host CPU,
+in the session that wrote the file: the same torch build as everywhere else; between CPU models MKL may pick kernels with another
+summation order, i.e. differences at fp32 rounding level, three orders of magnitude inside the T2 bound the tests apply); a miss -- a
+kernel change that moves a population by one ulp, a new case -- computes the oracle as before and, when HIPETS_ORACLE_CACHE_OUT
+names a directory, writes the merged file there for committing (profiles/session_full.sh sets it; copy gpurun_out/oracle_cache/*.npz
+to tests/golden/oracle_cache/).  HIPETS_ORACLE_CACHE=0 ignores the stored entries: the suite then runs exactly as in round 3.
+Nothing here touches the product, and the comparison the tests make is unchanged.  A stale entry (say, after a change of the Philox
+counter layout that the seed-keyed entries cannot see) can only make a test FAIL: the device side is always computed afresh."""
 import hashlib
 import os
 
