@@ -413,7 +413,10 @@ HID200_CASES = [SIZES[12], SIZES[13], SIZES[14],
                 (11, 3, 60, 5, 6, dict(ensemble_size=5, hid=200, termination="hopper", normalizer="f32")),
                 (17, 6, 40, 6, 5, dict(ensemble_size=3, hid=200, propagation="fixed_model", learned_rewards=True, reward=None)),
                 (23, 7, 25, 4, 4, dict(ensemble_size=4, hid=208, reward="pusher", propagation="expectation")),
-                (6, 2, 33, 5, 5, dict(ensemble_size=5, hid=193, deterministic=True, normalizer="none"))]
+                (6, 2, 33, 5, 5, dict(ensemble_size=5, hid=193, deterministic=True, normalizer="none")),
+                # other depths: the hidden-static path serves "the first op", "every op whose K and N are the hidden width", "the last op"
+                (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=200, num_layers=1)),
+                (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=200, num_layers=6, termination="walker2d"))]
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])
