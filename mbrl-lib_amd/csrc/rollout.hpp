@@ -1388,8 +1388,10 @@ template <int R, class S> struct MinWaves { static constexpr int value = S::WIDE
 // workgroup at four points of every step of the persistent DEVICE form, behind the phase-cycle table of the caller's buffer.
 #ifdef HIPETS_STEP_TRACE
 #define HIPETS_STAMP(k, step)                                                                                                     \
-    do {                                                                                                                          \
-        if (persist && ra.phase_cycles && tid == 0) ra.phase_cycles[128 + ((size_t)blockIdx.x * ra.H + (step)) * 4 + (k)] = wall_clock64(); \
+    do {  /* one record per (launched workgroup, step, turn): stamp_seq = the (step, turn) sequence index of the step loop */     \
+        (void)(step);                                                                                                             \
+        if (persist && ra.phase_cycles && tid == 0 && n_serve <= 4)                                                                \
+            ra.phase_cycles[128 + ((size_t)blockIdx.x * (ra.H * 4) + stamp_seq) * 4 + (k)] = wall_clock64();  /* stride: <= 4 turns per step */ \
     } while (0)
 #else
 #define HIPETS_STAMP(k, step) do {} while (0)
@@ -1539,7 +1541,18 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     // rows wider than a few pairs (cfg4: 24 pairs per row, cfg4': 189) are collected in rounds of kGT pairs per thread, each round one
     // round trip to the table (>= 1 us even when the rows are long there: the later turns of a step): 4 / 8 in flight instead of 2
     // cut cfg4''s 12 rounds per turn to 3.  (Only the collect phase holds these registers; the straight form's cfg2 needs one round.)
-    constexpr int kGT = S::WIDE ? 8 : ((kLean && S::OUTC >= 4) ? 4 : kG);
+    // (round 4, step trace of the turn-based form, profiles/turn_trace.py + r4_turn_trace.json: cfg4' spends 9.5 us per turn in its
+    // three rounds of 8 and 8.3 us between "my rows arrived" and "input built"; MORE pairs in flight measured SLOWER -- 16 per thread
+    // for the WIDE instances: 9.84 -> 10.36 ms per cfg4' rollout (the per-item state of the retry loop pushes the kernel's
+    // accumulators into AccVGPR spill space: 98 -> 126), 8 instead of 4 for cfg4: 3.37 -> 3.41 ms -- and HALVING the hand-over
+    // traffic changed nothing (9.84 vs 9.89 ms): the phase is bound by round-trip latency and its own bookkeeping, not by bandwidth)
+#ifndef HIPETS_COLLECT_WIDE
+#define HIPETS_COLLECT_WIDE 8
+#endif
+#ifndef HIPETS_COLLECT_OUT4
+#define HIPETS_COLLECT_OUT4 4
+#endif
+    constexpr int kGT = S::WIDE ? HIPETS_COLLECT_WIDE : ((kLean && S::OUTC >= 4) ? HIPETS_COLLECT_OUT4 : kG);
     int xs[kG], xv[kG];
 #pragma unroll
     for (int q = 0; q < kG; ++q) {
@@ -1716,9 +1729,22 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     int kq = Kp0 >> 2;  // column quads per row (the padded input width is a multiple of 16; bf16x3: of 32, set once the layer table is in LDS)
     // The (wave-uniform) normaliser / obs-preprocess switches are resolved ONCE per call into a compile-time variant:
     // with the switches inside, each of the four elements became its own chain of scalar branches and waits.
+    // Item -> columns.  The fp32 image stores, inside every 16-wide k chunk, the 4 x 4 block (k-step, lane group) transposed
+    // (lds_col): the four columns {16 kk + 4 q + g : q = 0..3} of lane group g sit at the CONSECUTIVE positions 16 kk + 4 g .. + 3.
+    // An item is therefore (row, chunk kk, group g) with those four columns (round 4): ONE ds_write_b128 instead of four scattered
+    // ds_write_b32, and consecutive threads read consecutive state floats / normaliser doubles (conflict free) where the old item
+    // (four CONSECUTIVE columns) read with a stride of four (measured on cfg4', 393 columns x 32 rows: 8.3 us per turn in the step
+    // trace, profiles/turn_trace.py).  Same arithmetic per element.  bf16x3 images keep consecutive columns (split3x4's layout).
+#ifndef HIPETS_INPUT_BY_GROUP
+#define HIPETS_INPUT_BY_GROUP 1
+#endif
     auto build_input_impl = [&](const int t, float* const dst, auto norm_tag, auto plain_tag) __attribute__((always_inline)) {
         constexpr int NORM = decltype(norm_tag)::value;
         constexpr bool PLAIN = decltype(plain_tag)::value;
+        // (shape-specialised instances WITH obs preprocessing keep the old items: their input is narrow, this function runs in their
+        // prologue and turn-based flows only, and the R = 2 halfcheetah DEVICE instance -- at the 256-register limit of two waves per
+        // SIMD -- spilt one VGPR to scratch with four sinf / cosf-bearing elements held for one store)
+        constexpr bool kByGroup = HIPETS_INPUT_BY_GROUP && !kB3 && (PLAIN || !kLean);
         const float* actn_t = sm.actn + (t & 1) * n_act;
         for (int i = tid; i < ROWS * kq; i += kThreads) {
             const int s = i / kq, cq = i % kq;
@@ -1726,7 +1752,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = 4 * cq + q;
+                const int c = kByGroup ? ((cq >> 2) << 4) + 4 * q + (cq & 3) : 4 * cq + q;
                 const int cc = min(c, md.in_dim - 1);  // clamped index: loads stay in bounds, result masked below
                 float x;
                 if (cc < md.obs_in) {
@@ -1750,6 +1776,8 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 char* row = reinterpret_cast<char*>(dst) + (size_t)s * ld_in * 4;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(row + b3_offset(4 * cq, p)) = pc[p];
+            } else if constexpr (kByGroup) {  // columns 16 kk + 4 q + g live at positions 16 kk + 4 g + q: item cq = 4 kk + g writes [4 cq, 4 cq + 3]
+                *reinterpret_cast<f32x4*>(dst + s * ld_in + 4 * cq) = f32x4{v[0], v[1], v[2], v[3]};
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[s * ld_in + lds_col(4 * cq + q)] = v[q];
@@ -1851,6 +1879,8 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     // turns of the previous step); the later turns' rows arrived while the earlier ones computed.
     const int n_serve = persist ? (ra.n_logical - wg + (int)gridDim.x - 1) / (int)gridDim.x : 1;
     const int n_seq = (ra.t_end - ra.t_begin) * n_serve;
+    int stamp_seq = 0;  // (profiling builds: index of the current (step, turn) for HIPETS_STAMP)
+    (void)stamp_seq;
     // Straight persistent form (KSpec::FUSE instances, every launched workgroup serving exactly one logical workgroup, >= 3 hidden
     // layers): see the step loop.  The slot's rows of the current and of the next step live in two LDS arrays that swap roles.
 #ifdef HIPETS_DBG_NOSTRAIGHT
@@ -1947,6 +1977,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         HIPETS_STAMP(2, t_next - 1);  // this thread's rows have arrived
     };
     for (int q_seq = 0; q_seq < n_seq; ++q_seq) {
+        stamp_seq = q_seq;
         const int t = ra.t_begin + q_seq / n_serve;
         const bool more = t + 1 < ra.t_end;
         const bool has_next = q_seq + 1 < n_seq;  // persistent form: another (step, turn) follows
@@ -2391,13 +2422,17 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 for (int spins = 0;; ++spins) {
                     // issue, issue, wait as straight-line asm (no branch between a load and its wait: the compiler does not know the
                     // destination registers are still in flight); items with nothing to fetch read the table's first pair and ignore it
-                    static_assert(kGT == 2 || kGT == 4 || kGT == 8, "the wait below names its destinations");
+                    static_assert(kGT == 2 || kGT == 4 || kGT == 8 || kGT == 16 || kGT == 24, "the wait below names its destinations");
                     u32x4g got[kGT];
 #pragma unroll
                     for (int q = 0; q < kGT; ++q) pair_load_issue(got[q], src[q] ? src[q] : ra.exchange);
                     if constexpr (kGT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1])::"memory");
                     else if constexpr (kGT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3])::"memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]), "+v"(got[7])::"memory");
+                    else {  // (every 8 destinations one statement; the first is the wait, the others only tie their registers behind it)
+#pragma unroll
+                        for (int q8 = 0; q8 < kGT; q8 += 8)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[q8]), "+v"(got[q8 + 1]), "+v"(got[q8 + 2]), "+v"(got[q8 + 3]), "+v"(got[q8 + 4]), "+v"(got[q8 + 5]), "+v"(got[q8 + 6]), "+v"(got[q8 + 7])::"memory");
+                    }
                     bool ready = true;
 #pragma unroll
                     for (int q = 0; q < kGT; ++q)

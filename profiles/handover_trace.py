@@ -24,7 +24,7 @@ pop, H, P = int(os.environ.get("HANDOVER_POP", bench.POP)), bench.HORIZON, bench
 actions = (torch.rand(pop, H, bench.ACT, generator=g) * 2 - 1).to(dev)
 s0 = np.zeros(bench.OBS, np.float32)
 NWG = 256
-buf = torch.zeros(128 + NWG * H * 4, dtype=torch.int64, device=dev)
+buf = torch.zeros(128 + NWG * H * 4 * 4, dtype=torch.int64, device=dev)  # the kernel's record stride: H * 4 records per workgroup
 for i in range(200):  # warm the clocks up (the first rollouts after idle run ~5 % slower)
     eng.rollout(actions, s0, P, mode="device", seed=1, stream_id=i)
 res = []
@@ -32,7 +32,7 @@ for rep in range(5):
     buf.zero_()
     eng.rollout(actions, s0, P, mode="device", seed=1, stream_id=10 + rep, phase_cycles=buf[:128].view(8, 16))
     torch.cuda.synchronize()
-    st = buf[128:].view(NWG, H, 4).cpu().numpy().astype(np.float64) * 0.01  # 100 MHz ticks -> us
+    st = buf[128:].view(NWG, H * 4, 4).cpu().numpy().astype(np.float64)[:, :H] * 0.01  # 100 MHz ticks -> us (straight form: one record per step)
     live = st[:, 0, 0] > 0
     st = st[live]
     n = st.shape[0]
