@@ -46,14 +46,15 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the spar
 
 
 def synthetic_spec(device, precision="f32", obs=OBS, act=ACT, ensemble=ENSEMBLE, elite=None, obs_process="none", no_delta_list=(),
-                   reward="halfcheetah", termination="no_termination", seed=0):
+                   reward="halfcheetah", termination="no_termination", learned_rewards=False, seed=0):
     """Random-init GaussianMLP ensemble with the reference initialiser (models/util.py:15-28: truncated
     normal std 1/(2 sqrt(in)), zero bias; logvar bounds -10 / 0.5), built on the product side (no oracle)."""
     import hipets
 
     g = torch.Generator().manual_seed(seed)
     n_in = obs + (1 if obs_process == "cartpole_pets" else 0) + act
-    dims = [n_in] + [HID] * LAYERS + [2 * obs]
+    n_out = obs + (1 if learned_rewards else 0)  # one_dim_tr_model.py:287: the reward is the model's last output column
+    dims = [n_in] + [HID] * LAYERS + [2 * n_out]
     ws, bs = [], []
     for i in range(len(dims) - 1):
         std = 1.0 / (2.0 * np.sqrt(dims[i]))
@@ -62,10 +63,10 @@ def synthetic_spec(device, precision="f32", obs=OBS, act=ACT, ensemble=ENSEMBLE,
         ws.append(w.to(device))
         bs.append(torch.zeros(ensemble, 1, dims[i + 1], device=device))
     return hipets.ModelSpec(
-        weights=ws, biases=bs, obs_dim=obs, act_dim=act, min_logvar=-10 * torch.ones(1, obs), max_logvar=0.5 * torch.ones(1, obs),
+        weights=ws, biases=bs, obs_dim=obs, act_dim=act, min_logvar=-10 * torch.ones(1, n_out), max_logvar=0.5 * torch.ones(1, n_out),
         elite_models=elite, activation="silu", propagation="random_model", norm_mean=torch.zeros(1, n_in, dtype=torch.float64),
-        norm_std=torch.ones(1, n_in, dtype=torch.float64), target_is_delta=True, no_delta_list=list(no_delta_list), learned_rewards=False,
-        obs_process=obs_process, reward=reward, termination=termination, precision=precision)
+        norm_std=torch.ones(1, n_in, dtype=torch.float64), target_is_delta=True, no_delta_list=list(no_delta_list), learned_rewards=learned_rewards,
+        obs_process=obs_process, reward=None if learned_rewards else reward, termination=termination, precision=precision)
 
 
 # Other workloads on the same line (never `value`): the configurations the reference ships as its defaults, and the remaining
@@ -80,6 +81,9 @@ STOCK_WORKLOADS = {
     # conf/overrides/pets_cartpole.yaml:1-21 + util/env.py:71-74
     "pets_cartpole": dict(model=dict(obs=4, act=1, ensemble=7, elite=[1, 2, 4, 5, 6], reward="cartpole", termination="cartpole"),
                           optimizer="cem", pop=350, elite_ratio=0.1, alpha=0.1, P=20, H=15, source="conf/overrides/pets_cartpole.yaml"),
+    # conf/overrides/pets_pusher.yaml:1-20: learned reward (the model's last output column), no termination function
+    "pets_pusher": dict(model=dict(obs=20, act=7, ensemble=7, elite=[0, 1, 3, 4, 6], learned_rewards=True),
+                        optimizer="cem", pop=350, elite_ratio=0.1, alpha=0.1, P=20, H=25, source="conf/overrides/pets_pusher.yaml"),
 }
 OTHER_CONFIGS = {
     "configs[0] cfg1 cartpole": dict(model=dict(obs=4, act=1, ensemble=5, reward="cartpole", termination="cartpole"), optimizer="cem", pop=100,

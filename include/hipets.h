@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HIPETS_ABI_VERSION 4
+#define HIPETS_ABI_VERSION 5
 #define HIPETS_MAX_LAYERS 8
 
 typedef struct hipets_engine hipets_engine;
@@ -187,6 +187,23 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
  * member_schedule on such a model must size it with -1 and pass the reported row-tile count as opts->rows_per_group.        */
 int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t rows_per_group,
                          int32_t* n_workgroups, int32_t* row_tiles);
+
+/* Which instance of the rollout kernel a DEFAULT call (hipets_rollout / the fused plans with in-kernel randomness, no injected
+ * eps, no traces) of this size runs on the engine's model, and with how many row tiles per workgroup.  mode: HIPETS_MODE_FAST or
+ * HIPETS_MODE_DEVICE.  The instances compute the same arithmetic (the GPU suite compares them bit for bit); they differ in how
+ * much of the model's shape is a compile-time fact:
+ *   GENERIC        everything decided at run time (any widths, activations, propagation, normaliser)
+ *   HIDDEN_STATIC  SiLU models whose hidden layers are 193..208 wide -- the reference's default 200
+ *                  (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8) -- whatever their reward / termination / preprocessing
+ *   FUSED          hidden AND output layer shapes, reward / termination closed form (or learned reward) and obs preprocessing are
+ *                  compile-time facts; the output layer's accumulators feed the step's tail from registers (launch.hpp's tables:
+ *                  the BASELINE.json configurations and the conf/overrides/pets_*.yaml workloads without a termination function
+ *                  that reads every state dim)
+ *   WIDE           FUSED for output layers wider than 8 column tiles (Humanoid-v4)
+ * Diagnostic only -- nothing needs to call it; a profile (rocprofv3 --kernel-trace) shows the same thing as a kernel name.      */
+enum { HIPETS_KERNEL_GENERIC = 0, HIPETS_KERNEL_HIDDEN_STATIC = 1, HIPETS_KERNEL_FUSED = 2, HIPETS_KERNEL_WIDE = 3 };
+int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t mode, int32_t* kernel_class,
+                        int32_t* row_tiles);
 
 /* FAST-mode randomness, exported so a FAST rollout can be replayed through a reference implementation:
  * schedule DEVICE int32 [H, n_workgroups] = member slot of workgroup w at step t (workgroup w owns particle

@@ -648,6 +648,50 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     return 0;
 }
 
+int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizon, int32_t mode, int32_t* kernel_class, int32_t* row_tiles) {
+    if (!e || !e->has_model) return fail("engine has no model");
+    if (pop < 1 || P < 1 || horizon < 1) return fail("bad pop/horizon/particles");
+    if (mode != HIPETS_MODE_FAST && mode != HIPETS_MODE_DEVICE) return fail("hipets_kernel_class: mode must be HIPETS_MODE_FAST or HIPETS_MODE_DEVICE");
+    const ModelDev& md = e->md;
+    RolloutArgs probe{};  // what a default call's arguments look like to the launcher: in-kernel draws, nothing injected or traced
+    probe.use_philox = 1;
+    probe.mode = mode;
+    const bool call_lean = lean_call(md, probe);
+    long long tiles;
+    int slices;
+    if (mode == HIPETS_MODE_DEVICE) {  // rollout_impl's geometry: one slice of B / M rows per member
+        const long long B = (long long)pop * P;
+        const int domains = md.propagation == HIPETS_PROP_EXPECTATION ? 1 : md.M;
+        if (md.iid_members && domains > 1) return fail("DEVICE mode has no BasicEnsemble (iid member map) variant");
+        if (B % domains != 0) return fail("GaussianMLP ensemble requires batch size to be a multiple of the number of models. "
+                                          "Current batch size is %lld for %d models.", B, md.M);
+        tiles = (B / domains + kTile - 1) / kTile;
+        slices = domains;
+    } else {  // one slice of pop rows per particle
+        tiles = ((long long)pop + kTile - 1) / kTile;
+        slices = P;
+    }
+    const bool wide = wide_model(md) && call_lean;
+    const int R = choose_R(e, tiles, slices, 0, horizon, wide);
+    if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("the model does not fit LDS");
+    int cls = HIPETS_KERNEL_GENERIC;
+    if (md.precision == HIPETS_PREC_BF16X3) {
+        if (!(call_lean && b3_shape_exists(md, R))) return fail("bf16x3 arithmetic exists for the shape-specialised instances only");
+        cls = HIPETS_KERNEL_FUSED;
+    } else if (wide) {
+        cls = HIPETS_KERNEL_WIDE;
+    } else if (call_lean && !wide_model(md) && lean_shape_exists(md, R)) {
+        cls = HIPETS_KERNEL_FUSED;
+    } else {
+#define HIPETS_CLASS_HID(HC) if (hid_static_call(md, probe, HC)) cls = HIPETS_KERNEL_HIDDEN_STATIC;
+        HIPETS_HID_STATIC_SHAPES(HIPETS_CLASS_HID)
+#undef HIPETS_CLASS_HID
+    }
+    if (kernel_class) *kernel_class = cls;
+    if (row_tiles) *row_tiles = R;
+    return 0;
+}
+
 }  // extern "C"
 
 namespace {

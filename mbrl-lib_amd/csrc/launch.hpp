@@ -38,22 +38,32 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
 //   the workloads the reference ships (round 4): pets_halfcheetah (conf/overrides/pets_halfcheetah.yaml: obs 18 through
 //   HalfCheetahEnv.preprocess_fn, pop 400 x 20) R = 2 in DEVICE mode, 1 in FAST mode; pets_cartpole (pop 350 x 20) R = 1, 2;
 //   pets_cartpole_paper_version (cartpole_pets reward + CartPoleEnv.preprocess_fn, pop 500 x 20) R = 3.
+//   learned rewards + no_termination (pets_pusher 20 / 7, pets_reacher 17 / 7: pop 350 x 20; pets_mppi_halfcheetah: obs 18 through
+//   preprocess_fn, MPPI 350 x 20): output layers of 3 column tiles like cfg2's, R = 2 in DEVICE mode, 1 in FAST mode.
 #define HIPETS_LEAN_SHAPES_R1(X)                                                                                                               \
     X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
-    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
+    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
 #define HIPETS_LEAN_SHAPES_R2(X)                                                                                                               \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
     X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
-    X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE)
+    X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE)                                                                        \
+    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
 #define HIPETS_LEAN_SHAPES_R3(X)                                                                                                               \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS)
 #define HIPETS_LEAN_SHAPES_R4(X) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE)
 
+// bf16x3 precision instances per R: X(hidden column tiles, output column tiles, reward fn, termination fn); no obs preprocessing
+#define HIPETS_B3_SHAPES_R1(X) X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE)
+#define HIPETS_B3_SHAPES_R2(X) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE)
+#define HIPETS_B3_SHAPES_R3(X) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID)
+#define HIPETS_B3_SHAPES_R4(X)
+
 // the model-side facts every lean fp32 instance shares (the call-side ones: lean_call below)
 inline bool lean_model(const ModelDev& md) {
     return md.precision == HIPETS_PREC_F32 && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 && !md.deterministic &&
-           md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1;
+           md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && (md.reward_fn != HIPETS_REW_LEARNED || md.learned_rewards);
 }
 
 // is there a lean fp32 instance of this model's shape for R row tiles? (what the launcher of rollout_r<R>.hip will find; the cost
@@ -70,6 +80,20 @@ inline bool lean_shape_exists(const ModelDev& md, const int R) {
         default: break;
     }
 #undef HIPETS_HAS_SHAPE
+    return false;
+}
+
+// ... and the same question for the bf16x3 instances (rollout_inst.inc's HIPETS_TRY_B3)
+inline bool b3_shape_exists(const ModelDev& md, const int R) {
+#define HIPETS_HAS_B3(HC, OC, RW, TM) \
+    if (md.hidC == HC && md.outC == OC && md.reward_fn == RW && md.term_fn == TM && md.obs_process == HIPETS_OBS_NONE) return true;
+    switch (R) {
+        case 1: HIPETS_B3_SHAPES_R1(HIPETS_HAS_B3) break;
+        case 2: HIPETS_B3_SHAPES_R2(HIPETS_HAS_B3) break;
+        case 3: HIPETS_B3_SHAPES_R3(HIPETS_HAS_B3) break;
+        default: break;
+    }
+#undef HIPETS_HAS_B3
     return false;
 }
 

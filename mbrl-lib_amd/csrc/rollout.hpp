@@ -1120,9 +1120,12 @@ struct KSpec {
     // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
     static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && (OUTC_ <= kSplMaxTiles || WIDE);
     static constexpr bool SPL_OUT = OUTC_ >= 0 && OUTC_ <= kSplMaxTiles;  // the output layer sums even / odd k-steps separately (wave_gemm SPL)
-    static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS) &&
+    static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS || REW_ == HIPETS_REW_LEARNED) &&
                             (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID)),
                   "fused tail: the reward / termination lane sees dims 0..3 of its row");
+    // learned rewards (round 4; pets_pusher / pets_reacher / pets_mppi_halfcheetah): the reward is the sampled LAST output column, so the
+    // lane that holds that column keeps the row's running total -- which sees no state dim at all: no termination function then
+    static_assert(!FUSE || REW_ != HIPETS_REW_LEARNED || (TERM_ == HIPETS_TERM_NONE && !WIDE), "fused tail with learned rewards: no_termination only");
     // obs preprocessing in the fused tail (round 4): the lane that holds the trig dim writes its sin and cos columns (ObsMap)
     static_assert(!FUSE || (NORM_ == HIPETS_NORM_F64 && (OBSP_ == HIPETS_OBS_NONE || !WIDE)), "fused tail: f64 normaliser; WIDE instances: no obs preprocessing");
     static_assert(!FUSE || OBSP_ == HIPETS_OBS_NONE || OBSP_ == HIPETS_OBS_HALFCHEETAH || OBSP_ == HIPETS_OBS_CARTPOLE_PETS, "unknown obs preprocessing");
@@ -2102,15 +2105,21 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 // the inactive lanes' stores to one spare row instead made every workgroup's write-through stores queue on ONE
                 // address (measured: 1.375 vs 1.081 ms per cfg2 rollout)
                 if (handover && okA) pair_store(handover + (size_t)rid * NV + d0, pubA, pubB, handover_tg);
-                if (c == 0) {  // wave-uniform.  Reward, termination, masked accumulation (model_env.py:124-129, :186-188) by the lane that holds
-                               // dims 0, 1 of the row; dims 2, 3 sit in the next lane group of the same accumulator.  (A wave can hold
-                               // several c == 0 units -- one per row tile when the output layer has >= 4 column tiles -- hence here, per unit.)
-                    float st[4];
-                    st[0] = okA ? vA : 0.f;
-                    st[1] = okB ? vB : 0.f;
-                    st[2] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubA));
-                    st[3] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubB));
-                    if (g == 0 && rid >= 0) {
+                // Reward, termination, masked accumulation (model_env.py:124-129, :186-188) by ONE lane per row: closed forms -- the lane
+                // that holds dims 0, 1 of the row (dims 2, 3 sit in the next lane group of the same accumulator); learned rewards -- the
+                // lane that holds output column obs_dim, whose sampled value IS the reward (one_dim_tr_model.py:287).  (A wave can hold
+                // several such units -- one per row tile when the output layer has >= 4 column tiles -- hence here, per unit.)
+                constexpr bool kLearnedRew = S::REW == HIPETS_REW_LEARNED;
+                const int c_rew = kLearnedRew ? (md.obs_dim >> 3) : 0, g_rew = kLearnedRew ? ((md.obs_dim & 7) >> 1) : 0;
+                if (c == c_rew) {  // wave-uniform
+                    float st[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!kLearnedRew) {
+                        st[0] = okA ? vA : 0.f;
+                        st[1] = okB ? vB : 0.f;
+                        st[2] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubA));
+                        st[3] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubB));
+                    }
+                    if (g == g_rew && rid >= 0) {
                         float tot = sm.tot[s];
                         int trm = sm.term[s];
                         if (persist && sm.pend[s]) {  // collected late: the previous owner published them after ITS output layer (normally long arrived)
@@ -2132,7 +2141,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                             tot = __uint_as_float(gq[0]);
                             trm = (int)gq[2];
                         }
-                        float rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
+                        float rwd;
+                        if constexpr (kLearnedRew) rwd = (md.obs_dim & 1) ? predB : predA;  // = sample_impl's sm.lrew[s]
+                        else rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
                         const bool done = term_eval(st, 4, S::TERM);
                         if (trm) rwd = 0.f;
                         trm = trm | (done ? 1 : 0);

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HIPETS_LIB selects another build of the SAME library (kernel-variant experiments under profiles/); there is no fallback
 LIB_PATH = os.environ.get("HIPETS_LIB") or os.path.join(_HERE, "libhipets.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -22,6 +22,7 @@ ENSEMBLE = {"gaussian_mlp": 0, "basic_ensemble": 1}
 PREC = {"f32": 0, "bf16x3": 1}
 MODE_EXACT, MODE_FAST, MODE_DEVICE = 0, 1, 2
 MODES = {"exact": MODE_EXACT, "fast": MODE_FAST, "device": MODE_DEVICE}
+KERNEL_CLASSES = ("generic", "hidden_static", "fused", "wide")  # HIPETS_KERNEL_*
 
 
 class ModelDesc(C.Structure):
@@ -105,6 +106,7 @@ SYMBOLS = {
     "hipets_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RolloutOpts), _P, _P]),
     "hipets_step": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RolloutOpts), _P, _P, _P, _P]),
     "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hipets_kernel_class": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_fast_schedule": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_device_perms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),

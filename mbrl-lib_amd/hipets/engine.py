@@ -270,6 +270,13 @@ class Engine:
                                                   C.byref(r)))
         return nwg.value, r.value
 
+    def kernel_class(self, pop: int, num_particles: int, horizon: int, mode: str = "device"):
+        """(class name, row tiles per workgroup) of the rollout-kernel instance a default rollout / fused plan of this size runs on
+        the engine's model: "generic", "hidden_static", "fused" or "wide" (include/hipets.h, hipets_kernel_class).  Diagnostic."""
+        cls, r = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.hipets_kernel_class(self._h, pop, num_particles, horizon, _lib.MODES[mode], C.byref(cls), C.byref(r)))
+        return _lib.KERNEL_CLASSES[cls.value], r.value
+
     def fast_schedule(self, horizon: int, n_workgroups: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:
         """The member schedule a FAST rollout with (seed, stream_id) uses: int32 [H, n_workgroups]."""
         out = torch.empty(horizon, n_workgroups, dtype=torch.int32, device=self.device)

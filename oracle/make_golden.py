@@ -329,6 +329,15 @@ FULL_CASES = {
     "stock_cartpole": dict(obs=4, act=1, mkw=dict(ensemble_size=7, hid=200, seed=35, elite=[1, 2, 4, 5, 6], reward="cartpole",
                                                   termination="cartpole"),
                            pop=350, P=20, H=15, iters=5, optimizer="cem", elite_ratio=0.1, alpha=0.1),
+    # conf/overrides/pets_pusher.yaml:1-20: obs 20 / act 7, LEARNED reward (the model's last output column, one_dim_tr_model.py:287),
+    # no termination function, pop 350, elite ratio 0.1, alpha 0.1, P 20, H 25
+    "stock_pusher": dict(obs=20, act=7, mkw=dict(ensemble_size=7, hid=200, seed=36, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None),
+                         pop=350, P=20, H=25, iters=5, optimizer="cem", elite_ratio=0.1, alpha=0.1),
+    # conf/overrides/pets_mppi_halfcheetah.yaml:1-24: the pets_halfcheetah model (obs 18 through preprocess_fn, no_delta_list [0]) with
+    # a learned reward, planned by MPPI: pop 350, gamma 0.9, sigma 1.0, beta 0.9, P 20, H 30
+    "stock_mppi_halfcheetah": dict(obs=18, act=6, mkw=dict(ensemble_size=7, hid=200, seed=37, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah",
+                                                           no_delta_list=[0], learned_rewards=True, reward=None),
+                                   pop=350, P=20, H=30, iters=5, optimizer="mppi"),
 }
 
 

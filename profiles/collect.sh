@@ -26,7 +26,7 @@ for c in cfg1_cartpole cfg4_humanoid_truncated_obs cfg4_humanoid_v4_obs376 cfg5_
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_$c -o t -- python profiles/other_configs.py --only $c --mode device --reps 5 > $OUT/cfg_$c.log 2>&1
 done
 # the workloads the reference ships (round 4): kernel trace of their rollouts, both randomness modes
-for W in stock_halfcheetah stock_cartpole; do
+for W in stock_halfcheetah stock_cartpole stock_pusher; do
   for MODE in device fast; do
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_${W}_$MODE -o t -- python profiles/stock_workloads.py --only $W --mode $MODE --reps 10 --no-plans > $OUT/cfg_${W}_$MODE.log 2>&1
   done

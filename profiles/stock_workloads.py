@@ -30,6 +30,11 @@ WORKLOADS = {
     "cfg2_synthetic": (17, 6, dict(ensemble_size=5), 500, 20, 30, 0.1, 0.1),
     "stock_halfcheetah": (18, 6, dict(ensemble_size=7, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0]), 400, 20, 30, 0.16, 0.12),
     "stock_cartpole": (4, 1, dict(ensemble_size=7, elite=[1, 2, 4, 5, 6], reward="cartpole", termination="cartpole"), 350, 20, 15, 0.1, 0.1),
+    # learned rewards, no termination function: conf/overrides/pets_pusher.yaml, pets_reacher.yaml, pets_mppi_halfcheetah.yaml (its model)
+    "stock_pusher": (20, 7, dict(ensemble_size=7, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None), 350, 20, 25, 0.1, 0.1),
+    "stock_reacher": (17, 7, dict(ensemble_size=7, elite=[0, 1, 3, 4, 6], no_delta_list=[0], learned_rewards=True, reward=None), 350, 20, 15, 0.1, 0.1),
+    "stock_mppi_halfcheetah_model": (18, 6, dict(ensemble_size=7, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0],
+                                                 learned_rewards=True, reward=None), 350, 20, 30, 0.1, 0.1),
 }
 
 
@@ -78,7 +83,8 @@ def main():
         s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
         fl = flops(om)
         nwg, r = eng.fast_geometry(pop, P, H, 0)
-        res = {"flop_per_candidate_step": fl, "candidate_steps_per_rollout": pop * P * H, "fast_geometry": {"workgroups": nwg, "row_tiles": r}}
+        res = {"flop_per_candidate_step": fl, "candidate_steps_per_rollout": pop * P * H, "fast_geometry": {"workgroups": nwg, "row_tiles": r},
+               "kernel_class": {m: list(eng.kernel_class(pop, P, H, m)) for m in ("device", "fast")}}
         for mode in modes:
             variants = [("default", dict())]
             if args.generic:

@@ -135,7 +135,7 @@ if tcc:
         per["l2_hit_frac"] = per.get("TCC_HIT_sum", 0.0) / (per.get("TCC_HIT_sum", 0.0) + per.get("TCC_MISS_sum", 1.0))
     json.dump({"workload": "cfg2 rollout, precision bf16x3, DEVICE mode (persistent form, XCD-major workgroup order)", "per_launch": per},
               open(os.path.join(dst, f"{tag}_bf16x3_l2.json"), "w"), indent=1)
-for w in ("stock_halfcheetah", "stock_cartpole"):  # the raw rocprofv3 statistics of the shipped workloads' rollouts, verbatim
+for w in ("stock_halfcheetah", "stock_cartpole", "stock_pusher"):  # the raw rocprofv3 statistics of the shipped workloads' rollouts, verbatim
     for mode in ("device", "fast"):
         st = sorted(glob.glob(os.path.join(src, f"cfg_{w}_{mode}", "**", "t_kernel_stats.csv"), recursive=True))
         if st:

@@ -82,11 +82,11 @@ def elites_agree(dev_idx, ref_values, K):
 
 
 @pytest.mark.parametrize("mode", ["device", "fast"])
-@pytest.mark.parametrize("case_name", ["cfg2_cem", "stock_halfcheetah", "stock_cartpole"])
+@pytest.mark.parametrize("case_name", ["cfg2_cem", "stock_halfcheetah", "stock_cartpole", "stock_pusher"])
 def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode, case_name):
     """cfg2_cem = BASELINE.json configs[1]; stock_halfcheetah / stock_cartpole = the workloads the reference ships
     (conf/overrides/pets_halfcheetah.yaml, pets_cartpole.yaml: obs preprocessing + no_delta_list + 7 members / 5 elites, their own
-    population sizes, elite ratios and alphas)."""
+    population sizes, elite ratios and alphas); stock_pusher (pets_pusher.yaml) = a learned reward in the fused tail."""
     c, om, s0 = make_case(case_name)
     obs, act, P, H, pop, iters = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"]
     ratio, alpha = c.get("elite_ratio", 0.1), c.get("alpha", 0.1)
@@ -135,8 +135,11 @@ def test_fused_cem_plan_cfg2_replayed_through_oracle(engine, mode, case_name):
 
 
 @pytest.mark.parametrize("mode", ["device", "fast"])
-def test_fused_mppi_plan_cfg5_replayed_through_oracle(engine, mode):
-    c, om, s0 = make_case("cfg5_mppi")
+@pytest.mark.parametrize("case_name", ["cfg5_mppi", "stock_mppi_halfcheetah"])
+def test_fused_mppi_plan_cfg5_replayed_through_oracle(engine, mode, case_name):
+    """cfg5_mppi = BASELINE.json configs[4]; stock_mppi_halfcheetah = conf/overrides/pets_mppi_halfcheetah.yaml (obs preprocessing,
+    no_delta_list, learned reward, 7 members / 5 elites, pop 350)."""
+    c, om, s0 = make_case(case_name)
     obs, act, P, H, pop, iters = c["obs"], c["act"], c["P"], c["H"], c["pop"], c["iters"]
     fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=6, mode=mode)
     lower, upper = -torch.ones(H, act), torch.ones(H, act)

@@ -91,6 +91,12 @@ SIZES = [
     # the other PETS obs preprocessor (env/pets_cartpole.py:78-101: [sin s1, cos s1, s0, s2:], one input column more than obs dims) with
     # its reward function, in-kernel randomness
     (4, 1, 80, 5, 6, dict(ensemble_size=5, hid=200, obs_process="cartpole_pets", reward="cartpole_pets")),
+    # shipped workloads with LEARNED rewards and no termination function, at full size: pets_pusher (conf/overrides/pets_pusher.yaml:
+    # obs 20 / act 7, pop 350 x 20 particles, H 25) and pets_mppi_halfcheetah (pets_mppi_halfcheetah.yaml: obs 18 through
+    # preprocess_fn, no_delta_list [0], 350 x 20, H 30): the reward is the sampled last output column (one_dim_tr_model.py:287)
+    (20, 7, 350, 20, 25, dict(ensemble_size=7, hid=200, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None)),
+    (18, 6, 350, 20, 30, dict(ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0],
+                              learned_rewards=True, reward=None)),
 ]
 # in-kernel randomness replays (FAST / DEVICE): everything but the expectation-propagation f32-normaliser case in FAST
 FAST_SIZES = SIZES[:9] + SIZES[10:]
@@ -416,7 +422,14 @@ HID200_CASES = [SIZES[12], SIZES[13], SIZES[14],
                 (6, 2, 33, 5, 5, dict(ensemble_size=5, hid=193, deterministic=True, normalizer="none")),
                 # other depths: the hidden-static path serves "the first op", "every op whose K and N are the hidden width", "the last op"
                 (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=200, num_layers=1)),
-                (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=200, num_layers=6, termination="walker2d"))]
+                (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=200, num_layers=6, termination="walker2d")),
+                # learned rewards in the fused tail (pets_pusher, pets_mppi_halfcheetah at full size; pets_reacher's shape): the lane
+                # that holds output column obs_dim keeps the row's total -- first / second dim of its pair, first / last lane group,
+                # the first column of a tile
+                SIZES[15], SIZES[16],
+                (17, 7, 64, 5, 6, dict(ensemble_size=5, hid=200, no_delta_list=[0], learned_rewards=True, reward=None)),
+                (16, 3, 40, 5, 5, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None)),
+                (23, 4, 40, 5, 5, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None))]
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])
@@ -435,6 +448,52 @@ def test_hidden_static_instances_equal_the_generic_kernel_bitwise(engine, case, 
     a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+# conf/overrides/pets_*.yaml as synthetic models of the same shape (conf/dynamics_model/gaussian_mlp_ensemble.yaml: 7 members / 5 elites,
+# 4 x 200 SiLU): (name, obs, act, pop, H, model kwargs, instance class of a default rollout).  INTEGRATION.md section 3a is this table.
+SHIPPED = [
+    ("pets_halfcheetah", 18, 6, 400, 30, dict(obs_process="halfcheetah", no_delta_list=[0]), "fused"),
+    ("pets_cartpole", 4, 1, 350, 15, dict(reward="cartpole", termination="cartpole"), "fused"),
+    ("pets_cartpole_paper_version", 4, 1, 500, 30, dict(obs_process="cartpole_pets", reward="cartpole_pets"), "fused"),
+    ("pets_mppi_halfcheetah", 18, 6, 350, 30, dict(obs_process="halfcheetah", no_delta_list=[0], learned_rewards=True, reward=None), "fused"),
+    ("pets_pusher", 20, 7, 350, 25, dict(learned_rewards=True, reward=None), "fused"),
+    ("pets_reacher", 17, 7, 350, 15, dict(no_delta_list=[0], learned_rewards=True, reward=None), "fused"),
+    # termination functions that read EVERY state dim (termination_fns.py:22-44: isfinite(next_obs).all(), |next_obs[1:]| < 100) need a
+    # reduction across the row's lanes and waves: not in the fused tail
+    ("pets_hopper", 11, 3, 350, 30, dict(learned_rewards=True, reward=None, termination="hopper"), "hidden_static"),
+    ("pets_inv_pendulum", 4, 1, 480, 45, dict(learned_rewards=True, reward=None, termination="inverted_pendulum"), "hidden_static"),
+]
+
+
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("wl", SHIPPED, ids=lambda w: w[0])
+def test_shipped_workloads_run_the_instance_class_the_docs_say(engine, wl, mode):
+    """hipets_kernel_class: which instance of the rollout kernel a default call runs.  Every workload the reference ships gets at
+    least the hidden-static instance, and the ones without an all-dims termination function the fused one; forcing the generic
+    kernel returns the same bits (the arithmetic is the same in all classes)."""
+    name, obs, act, pop, H, mkw, want = wl
+    om, actions, s0, _, _ = _random_case(obs, act, pop, 20, 3, ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    cls, r = engine.kernel_class(pop, 20, H, mode)
+    assert cls == want and 1 <= r <= 4
+    a = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r)
+    b = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_kernel_class_of_other_models(engine):
+    om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=64)
+    engine.set_model(to_spec(om, 17, 6))
+    assert engine.kernel_class(500, 20, 30, "device")[0] == "generic"
+    om, *_ = _random_case(376, 17, 8, 5, 2, ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")
+    engine.set_model(to_spec(om, 376, 17))
+    assert engine.kernel_class(1036, 20, 40, "device") == ("wide", 2)
+    om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=200)
+    engine.set_model(to_spec(om, 17, 6))
+    assert engine.kernel_class(500, 20, 30, "device") == ("fused", 3)  # BASELINE.json configs[1]
+    with pytest.raises(Exception, match="mode must be"):
+        engine.kernel_class(500, 20, 30, "exact")
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])
