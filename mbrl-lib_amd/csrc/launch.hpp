@@ -49,9 +49,11 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
     X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
     X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE)                                                                        \
     X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
+//   pets_inv_pendulum (learned reward + the inverted_pendulum termination function, obs 4 / act 1, pop 480 x 20): R = 3.
 #define HIPETS_LEAN_SHAPES_R3(X)                                                                                                               \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
-    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS)
+    X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS) \
+    X(13, 1, HIPETS_REW_LEARNED, HIPETS_TERM_INVERTED_PENDULUM, HIPETS_OBS_NONE)
 #define HIPETS_LEAN_SHAPES_R4(X) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE)
 
 // bf16x3 precision instances per R: X(hidden column tiles, output column tiles, reward fn, termination fn); no obs preprocessing
@@ -60,10 +62,19 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
 #define HIPETS_B3_SHAPES_R3(X) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID)
 #define HIPETS_B3_SHAPES_R4(X)
 
+// what the fused tail's reward / termination lane can see of THIS model: termination functions that test every state dim need all of them
+// among the four it holds; a learned reward next to a termination function comes from another lane of the same accumulator (column
+// tile 0 holds output columns 0..7)
+inline bool fused_term_ok(const ModelDev& md) {
+    if (md.term_fn == HIPETS_TERM_INVERTED_PENDULUM && md.obs_dim > 4) return false;
+    if (md.reward_fn == HIPETS_REW_LEARNED && md.term_fn != HIPETS_TERM_NONE && md.obs_dim >= 8) return false;
+    return true;
+}
+
 // the model-side facts every lean fp32 instance shares (the call-side ones: lean_call below)
 inline bool lean_model(const ModelDev& md) {
     return md.precision == HIPETS_PREC_F32 && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 && !md.deterministic &&
-           md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && (md.reward_fn != HIPETS_REW_LEARNED || md.learned_rewards);
+           md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && (md.reward_fn != HIPETS_REW_LEARNED || md.learned_rewards) && fused_term_ok(md);
 }
 
 // is there a lean fp32 instance of this model's shape for R row tiles? (what the launcher of rollout_r<R>.hip will find; the cost
@@ -101,7 +112,7 @@ inline bool b3_shape_exists(const ModelDev& md, const int R) {
 // of an instance's shape since round 4)
 inline bool lean_call(const ModelDev& md, const RolloutArgs& ra) {
     return !ra.generic_only && md.activation == HIPETS_ACT_SILU && md.normalizer == HIPETS_NORM_F64 &&
-           !md.deterministic && md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && !ra.eps && ra.use_philox &&
+           !md.deterministic && md.propagation != HIPETS_PROP_EXPECTATION && md.lv_rows == 1 && fused_term_ok(md) && !ra.eps && ra.use_philox &&
 #if defined(HIPETS_STEP_TRACE) || (defined(HIPETS_LEAN_PROF) && HIPETS_LEAN_PROF)
            !ra.trace_next_obs && !ra.trace_rewards && ra.pop_env == 0 && !ra.init_states && !ra.write_back;  // the stamps go to phase_cycles
 #else

@@ -1120,12 +1120,16 @@ struct KSpec {
     // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
     static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && (OUTC_ <= kSplMaxTiles || WIDE);
     static constexpr bool SPL_OUT = OUTC_ >= 0 && OUTC_ <= kSplMaxTiles;  // the output layer sums even / odd k-steps separately (wave_gemm SPL)
+    // termination functions that test EVERY state dim (inverted_pendulum: isfinite(next_obs).all(), termination_fns.py:47-55) are fused for
+    // models with obs_dim <= 4 only -- then dims 0..3 ARE every dim (launch.hpp fused_term_ok checks the model)
     static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS || REW_ == HIPETS_REW_LEARNED) &&
-                            (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID)),
+                            (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID || TERM_ == HIPETS_TERM_INVERTED_PENDULUM)),
                   "fused tail: the reward / termination lane sees dims 0..3 of its row");
-    // learned rewards (round 4; pets_pusher / pets_reacher / pets_mppi_halfcheetah): the reward is the sampled LAST output column, so the
-    // lane that holds that column keeps the row's running total -- which sees no state dim at all: no termination function then
-    static_assert(!FUSE || REW_ != HIPETS_REW_LEARNED || (TERM_ == HIPETS_TERM_NONE && !WIDE), "fused tail with learned rewards: no_termination only");
+    // learned rewards (round 4): the reward is the sampled LAST output column.  Without a termination function (pets_pusher / pets_reacher /
+    // pets_mppi_halfcheetah) the lane that holds that column keeps the row's running total and needs no state dim at all; with one
+    // (pets_inv_pendulum) the lane with dims 0, 1 keeps it and fetches the reward from the column's lane of the SAME accumulator, i.e. the
+    // column must sit in column tile 0: obs_dim < 8 (fused_term_ok)
+    static_assert(!FUSE || REW_ != HIPETS_REW_LEARNED || !WIDE, "fused tail with learned rewards: no WIDE instance");
     // obs preprocessing in the fused tail (round 4): the lane that holds the trig dim writes its sin and cos columns (ObsMap)
     static_assert(!FUSE || (NORM_ == HIPETS_NORM_F64 && (OBSP_ == HIPETS_OBS_NONE || !WIDE)), "fused tail: f64 normaliser; WIDE instances: no obs preprocessing");
     static_assert(!FUSE || OBSP_ == HIPETS_OBS_NONE || OBSP_ == HIPETS_OBS_HALFCHEETAH || OBSP_ == HIPETS_OBS_CARTPOLE_PETS, "unknown obs preprocessing");
@@ -2110,14 +2114,18 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 // lane that holds output column obs_dim, whose sampled value IS the reward (one_dim_tr_model.py:287).  (A wave can hold
                 // several such units -- one per row tile when the output layer has >= 4 column tiles -- hence here, per unit.)
                 constexpr bool kLearnedRew = S::REW == HIPETS_REW_LEARNED;
-                const int c_rew = kLearnedRew ? (md.obs_dim >> 3) : 0, g_rew = kLearnedRew ? ((md.obs_dim & 7) >> 1) : 0;
+                constexpr bool kRewLane = kLearnedRew && S::TERM == HIPETS_TERM_NONE;  // the reward column's lane keeps the total (else: the lane with dims 0, 1)
+                const int c_rew = kRewLane ? (md.obs_dim >> 3) : 0, g_rew = kRewLane ? ((md.obs_dim & 7) >> 1) : 0;
                 if (c == c_rew) {  // wave-uniform
                     float st[4] = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (!kLearnedRew) {
+                    float lrew = (md.obs_dim & 1) ? predB : predA;  // the learned reward, on the lane that holds output column obs_dim (= sample_impl's sm.lrew[s])
+                    if constexpr (!kRewLane) {
                         st[0] = okA ? vA : 0.f;
                         st[1] = okB ? vB : 0.f;
                         st[2] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubA));
                         st[3] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, (int)pubB));
+                        if constexpr (kLearnedRew)  // column obs_dim sits (md.obs_dim & 7) / 2 lane groups further in this accumulator
+                            lrew = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16 * ((md.obs_dim & 7) >> 1)) & 63) << 2, (int)__float_as_uint(lrew)));
                     }
                     if (g == g_rew && rid >= 0) {
                         float tot = sm.tot[s];
@@ -2142,7 +2150,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                             trm = (int)gq[2];
                         }
                         float rwd;
-                        if constexpr (kLearnedRew) rwd = (md.obs_dim & 1) ? predB : predA;  // = sample_impl's sm.lrew[s]
+                        if constexpr (kLearnedRew) rwd = lrew;
                         else rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
                         const bool done = term_eval(st, 4, S::TERM);
                         if (trm) rwd = 0.f;

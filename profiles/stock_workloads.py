@@ -35,6 +35,9 @@ WORKLOADS = {
     "stock_reacher": (17, 7, dict(ensemble_size=7, elite=[0, 1, 3, 4, 6], no_delta_list=[0], learned_rewards=True, reward=None), 350, 20, 15, 0.1, 0.1),
     "stock_mppi_halfcheetah_model": (18, 6, dict(ensemble_size=7, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0],
                                                  learned_rewards=True, reward=None), 350, 20, 30, 0.1, 0.1),
+    # conf/overrides/pets_inv_pendulum.yaml: learned reward + the inverted_pendulum termination function (every state dim)
+    "stock_inv_pendulum": (4, 1, dict(ensemble_size=7, elite=[0, 2, 3, 5, 6], learned_rewards=True, reward=None, termination="inverted_pendulum"),
+                           480, 20, 45, 0.078, 0.134484),
 }
 
 

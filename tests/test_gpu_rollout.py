@@ -97,6 +97,9 @@ SIZES = [
     (20, 7, 350, 20, 25, dict(ensemble_size=7, hid=200, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None)),
     (18, 6, 350, 20, 30, dict(ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0],
                               learned_rewards=True, reward=None)),
+    # pets_inv_pendulum (conf/overrides/pets_inv_pendulum.yaml: obs 4 / act 1, learned reward + the inverted_pendulum termination
+    # function -- isfinite over every state dim, termination_fns.py:47-55 --, pop 480 x 20 particles, H 45)
+    (4, 1, 480, 20, 45, dict(ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], learned_rewards=True, reward=None, termination="inverted_pendulum")),
 ]
 # in-kernel randomness replays (FAST / DEVICE): everything but the expectation-propagation f32-normaliser case in FAST
 FAST_SIZES = SIZES[:9] + SIZES[10:]
@@ -426,10 +429,14 @@ HID200_CASES = [SIZES[12], SIZES[13], SIZES[14],
                 # learned rewards in the fused tail (pets_pusher, pets_mppi_halfcheetah at full size; pets_reacher's shape): the lane
                 # that holds output column obs_dim keeps the row's total -- first / second dim of its pair, first / last lane group,
                 # the first column of a tile
-                SIZES[15], SIZES[16],
+                SIZES[15], SIZES[16], SIZES[17],
                 (17, 7, 64, 5, 6, dict(ensemble_size=5, hid=200, no_delta_list=[0], learned_rewards=True, reward=None)),
                 (16, 3, 40, 5, 5, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None)),
-                (23, 4, 40, 5, 5, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None))]
+                (23, 4, 40, 5, 5, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None)),
+                # ... next to a termination function that tests every state dim (pets_inv_pendulum: obs 4): the lane with dims 0, 1
+                # keeps the total and fetches the reward from the column's lane -- second / third lane group, second / first dim
+                (4, 1, 96, 5, 8, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None, termination="inverted_pendulum")),
+                (3, 1, 96, 5, 8, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None, termination="inverted_pendulum"))]
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])
@@ -459,10 +466,11 @@ SHIPPED = [
     ("pets_mppi_halfcheetah", 18, 6, 350, 30, dict(obs_process="halfcheetah", no_delta_list=[0], learned_rewards=True, reward=None), "fused"),
     ("pets_pusher", 20, 7, 350, 25, dict(learned_rewards=True, reward=None), "fused"),
     ("pets_reacher", 17, 7, 350, 15, dict(no_delta_list=[0], learned_rewards=True, reward=None), "fused"),
-    # termination functions that read EVERY state dim (termination_fns.py:22-44: isfinite(next_obs).all(), |next_obs[1:]| < 100) need a
-    # reduction across the row's lanes and waves: not in the fused tail
+    # a termination function that tests every state dim (termination_fns.py:47-55: isfinite(next_obs).all()) is fused where the four dims
+    # the reward / termination lane sees are all there are ...
+    ("pets_inv_pendulum", 4, 1, 480, 45, dict(learned_rewards=True, reward=None, termination="inverted_pendulum"), "fused"),
+    # ... and not otherwise (:12-26: |next_obs[1:]| < 100 over 11 dims is a reduction across the lanes and waves that share the row)
     ("pets_hopper", 11, 3, 350, 30, dict(learned_rewards=True, reward=None, termination="hopper"), "hidden_static"),
-    ("pets_inv_pendulum", 4, 1, 480, 45, dict(learned_rewards=True, reward=None, termination="inverted_pendulum"), "hidden_static"),
 ]
 
 
@@ -492,6 +500,11 @@ def test_kernel_class_of_other_models(engine):
     om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=200)
     engine.set_model(to_spec(om, 17, 6))
     assert engine.kernel_class(500, 20, 30, "device") == ("fused", 3)  # BASELINE.json configs[1]
+    # the inverted_pendulum termination function tests EVERY state dim: fused only where the tail's lane holds them all (obs_dim <= 4)
+    for obs, want in ((4, "fused"), (5, "hidden_static")):
+        om, *_ = _random_case(obs, 1, 8, 5, 2, ensemble_size=5, hid=200, learned_rewards=True, reward=None, termination="inverted_pendulum")
+        engine.set_model(to_spec(om, obs, 1))
+        assert engine.kernel_class(480, 20, 45, "device") == (want, 3)
     with pytest.raises(Exception, match="mode must be"):
         engine.kernel_class(500, 20, 30, "exact")
 
