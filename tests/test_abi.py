@@ -176,6 +176,16 @@ def test_isa_scanner_sees_both_hazards_of_an_asm_mfma(tmp_path):
     assert found == []
     n, found = scan(mfma + mfma.replace("v[30:33]", "v[40:43]") + "\tv_add_f32_e32 v1, v30, v2\n")  # 32 + 4 cycles < 40
     assert len(found) == 1
+    # control flow: a loop whose LAST instruction is an asm MFMA and whose FIRST reads that MFMA's result -- invisible top to bottom
+    # (the read comes first in the text), found along the back-edge; the same loop with the result drained before the branch is clean
+    loop = "\tv_mov_b32_e32 v9, 0\n.LBB0_1:\n\tv_add_f32_e32 v1, v30, v2\n\ts_nop 15\n" + mfma
+    n, found = scan(loop + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert n == 1 and len(found) == 1 and "in flight" in found[0] and "reached by a branch to .LBB0_1" in found[0]
+    n, found = scan(loop + "\ts_nop 15\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    assert found == []
+    # ... and a VALU write of an operand in the last slot before a forward branch into an MFMA
+    n, found = scan("\tv_mov_b64_e32 v[32:33], s[70:71]\n\ts_cbranch_scc0 .LBB0_2\n\ts_nop 7\n\ts_nop 7\n.LBB0_2:\n" + mfma)
+    assert len(found) == 1 and "writes a source" in found[0]
     # a compiler-issued MFMA (builtin, no asm markers) is the hazard recogniser's business, not the scan's
     n, found = scan("\tv_mov_b64_e32 v[32:33], s[70:71]\n\tv_mfma_f32_16x16x4_f32 v[30:33], v37, v53, v[30:33]\n")
     assert n == 0 and found == []
