@@ -194,7 +194,8 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, i
  * much of the model's shape is a compile-time fact:
  *   GENERIC        everything decided at run time (any widths, activations, propagation, normaliser)
  *   HIDDEN_STATIC  SiLU models whose hidden layers are 193..208 wide -- the reference's default 200
- *                  (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8) -- whatever their reward / termination / preprocessing
+ *                  (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8) --, 113..128 or 241..256 wide, whatever their reward /
+ *                  termination / preprocessing / output width
  *   FUSED          hidden AND output layer shapes, reward / termination closed form (or learned reward) and obs preprocessing are
  *                  compile-time facts; the output layer's accumulators feed the step's tail from registers (launch.hpp's tables:
  *                  the BASELINE.json configurations and the conf/overrides/pets_*.yaml workloads without a termination function

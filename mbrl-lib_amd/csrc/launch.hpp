@@ -21,8 +21,9 @@ hipError_t launch_rollout_r4(int grid, unsigned lds, int lds_max, const ModelDev
 #define HIPETS_WIDE_SHAPES(X) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID)
 
 // Hidden widths with a KSpec::HID_STATIC instance (hidden layers shape-specialised, everything else generic): X(hidden column tiles).
-// 13 tiles = hidden widths 193..208: the reference's default of 200 (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8).
-#define HIPETS_HID_STATIC_SHAPES(X) X(13)
+// 13 tiles = hidden widths 193..208: the reference's default of 200 (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8), which every
+// configuration it ships uses; 8 and 16 tiles = the power-of-two widths people change hid_size to (113..128, 241..256).
+#define HIPETS_HID_STATIC_SHAPES(X) X(13) X(8) X(16)
 
 // may this model / call run the hidden-static instance for `hc` hidden column tiles?  (SiLU, fp32 arithmetic, the LDS row stride the
 // instance was compiled for -- i.e. no layer wider than the hidden ones; RolloutArgs::generic_only == 1 forbids it, 2 allows it)

@@ -1207,7 +1207,10 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
         else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
         else linear_op<R, S::ACT, S::OUTC, false, NoTail, S::LD, (S::OUTC <= kSplMaxTiles), kHidChunks>(W, bias, lm, md.ld, false, md.activation, md.slope, in, out, wave, lane, prof);
     } else if constexpr (S::HID_STATIC) {
-        constexpr int kHidChunks = (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1;
+        // (unrolled up to 13 MFMA units per wave -- the widest the shape-specialised instances run: at 16 units, hid 256 with R = 4,
+        // the allocator splits accumulator live ranges inside the unrolled stream again and the build's ISA scan finds a v_mov of an
+        // accumulator behind an MFMA still in flight; the rolled loop ends every block with drain_all)
+        constexpr int kHidChunks = (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1 && ((S::HIDC + kWaves - 1) / kWaves) * R <= 13) ? S::HIDC : -1;
         if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
         else if (l < md.n_layers - 1) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, kHidChunks>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof);
         else if (lm.Np / kTile <= kSplMaxTiles)  // the output layer: the generic instance's dispatch, the SAME summation rule (SPL)

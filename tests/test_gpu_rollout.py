@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import hipets
 import oracle_cache as oc
 from conftest import GOLDEN, to_spec
 from oracle import pets_oracle as po
@@ -457,6 +458,38 @@ def test_hidden_static_instances_equal_the_generic_kernel_bitwise(engine, case, 
     assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
+# the other hidden widths with hidden-static instances: 8 and 16 column tiles (hid 113..128, 241..256)
+HIDW_CASES = [(17, 6, 500, 20, 4, dict(ensemble_size=5, hid=256)),
+              (17, 6, 40, 6, 5, dict(ensemble_size=3, hid=128)),
+              (11, 3, 60, 5, 6, dict(ensemble_size=5, hid=120, termination="hopper", normalizer="f32")),
+              (18, 6, 48, 5, 5, dict(ensemble_size=7, hid=250, elite=[0, 2, 3, 5, 6], obs_process="halfcheetah", no_delta_list=[0])),
+              (23, 7, 25, 4, 4, dict(ensemble_size=4, hid=128, reward="pusher", propagation="expectation")),
+              (6, 2, 33, 5, 5, dict(ensemble_size=5, hid=241, deterministic=True, normalizer="none")),
+              (17, 6, 30, 5, 4, dict(ensemble_size=5, hid=256, num_layers=2, propagation="fixed_model", learned_rewards=True, reward=None)),
+              (4, 1, 64, 5, 6, dict(ensemble_size=5, hid=113, num_layers=5, reward="cartpole", termination="cartpole"))]
+
+
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("rows_per_group", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("case", HIDW_CASES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+def test_hidden_static_instances_of_other_widths_equal_the_generic_kernel_bitwise(engine, case, mode, rows_per_group):
+    """SiLU models with 8 or 16 hidden column tiles (hid 113..128, 241..256 -- the reference ships 200 everywhere, but hid_size is the
+    first thing people change) get hidden-static instances too: same bits as the fully generic kernel for every row-tile count
+    that fits the LDS."""
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    engine.set_model(to_spec(om, obs, act))
+    assert engine.kernel_class(pop, P, H, mode)[0] == "hidden_static"
+    try:
+        a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
+    except hipets.HipetsError as exc:
+        if "does not fit LDS" in str(exc):
+            pytest.skip(f"R = {rows_per_group} does not fit the LDS at this width")
+        raise
+    b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
 # conf/overrides/pets_*.yaml as synthetic models of the same shape (conf/dynamics_model/gaussian_mlp_ensemble.yaml: 7 members / 5 elites,
 # 4 x 200 SiLU): (name, obs, act, pop, H, model kwargs, instance class of a default rollout).  INTEGRATION.md section 3a is this table.
 SHIPPED = [
@@ -491,9 +524,10 @@ def test_shipped_workloads_run_the_instance_class_the_docs_say(engine, wl, mode)
 
 
 def test_kernel_class_of_other_models(engine):
-    om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=64)
-    engine.set_model(to_spec(om, 17, 6))
-    assert engine.kernel_class(500, 20, 30, "device")[0] == "generic"
+    for hid, want in ((64, "generic"), (128, "hidden_static"), (256, "hidden_static"), (512, "generic")):
+        om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=hid)
+        engine.set_model(to_spec(om, 17, 6))
+        assert engine.kernel_class(500, 20, 30, "device")[0] == want
     om, *_ = _random_case(376, 17, 8, 5, 2, ensemble_size=7, hid=200, elite=[0, 1, 2, 3, 4], termination="humanoid")
     engine.set_model(to_spec(om, 376, 17))
     assert engine.kernel_class(1036, 20, 40, "device") == ("wide", 2)
