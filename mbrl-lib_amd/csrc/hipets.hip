@@ -186,7 +186,11 @@ size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
 // A CU holds two workgroups of an R <= 2 instance at once (256 registers each) and their fixed parts hide behind each other's MFMAs:
 // a pair costs a + 2 units; R >= 3 instances own the CU (512 registers) and their workgroups run one after the other.  A (shape, R)
 // pair without a shape-specialised instance (launch.hpp lean_shape_exists) runs the hidden-static or the generic kernel: + 8 %.
-// Calibrated on MI355X (profiles/r4_stock_workloads.json: every R forced, three workloads, both modes).
+// `desync`: the workgroups of the launch do not wait for each other (FAST mode: one launch for the horizon, no hand-over).  Two of them
+// on a CU then drift apart and their heavy waves stop meeting on a SIMD: a pair costs a + 2 x the AVERAGE units per SIMD (C R / 4: 3.25
+// instead of 4 per row tile at hid 200).  Step-synchronous launches (DEVICE / EXACT: hand-over or one launch per step) pay the busiest one.
+// Calibrated on MI355X (profiles/r4_stock_workloads.json, r4_learned_reward_workloads.json, r4_device_r_sweep.json: every R forced, 12
+// workloads, both modes -- the rule picks the fastest R in 23 of the 24 cases and loses 0.3 % in the other).
 int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (waves w and w + 4 share SIMD w % 4)
     const int full = C / kWaves, rem = C % kWaves, nu = rem * R;
     int simd[4] = {0, 0, 0, 0};
@@ -194,7 +198,7 @@ int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (w
     return std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
 }
 
-int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon, bool wide = false) {
+int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon, bool wide, bool desync) {
     if (forced > 0) return forced;
     const int C = e->md.hidC;
     const double a = 1.77 * (double)C / 13.0;  // the fixed part scales with the layer width like the units do
@@ -208,8 +212,9 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         const long long n = (nwg + e->num_cu - 1) / e->num_cu;  // workgroups the busiest CU serves
         const int co = (R <= 2 && !wide) ? 2 : 1;               // ... of which it holds this many at once
         const double u = wave_units(C, R);
+        const double u_pair = (co == 2 && desync) ? (double)C * R / 4.0 : u;
         const long long full = n / co, rem = n % co;
-        double cost = (double)full * (a + co * u) + (rem ? a + (double)rem * u : 0.0);
+        double cost = (double)full * (a + co * u_pair) + (rem ? a + (double)rem * u : 0.0);
         if (!lean_shape_exists(e->md, R)) cost *= 1.08;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
@@ -285,7 +290,7 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     }
     if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
     const long long tiles = (pop + kTile - 1) / kTile;
-    const int R = choose_R(e, tiles, P, 0, H, wide_model(md) && n_env == 1);  // the fused plans' rollouts are lean calls unless batched
+    const int R = choose_R(e, tiles, P, 0, H, wide_model(md) && n_env == 1, true);  // the fused plans' rollouts are lean calls unless batched
     const int nwg = (int)((tiles + R - 1) / R) * P;
     if (nwg > 8000) return 0;  // the rollout reports the error
     if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
@@ -640,7 +645,7 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     if (rows_per_group < -1 || rows_per_group > kMaxR) return fail("rows_per_group outside [-1, %d]", kMaxR);
     const long long tiles = (pop + kTile - 1) / kTile;
     const bool wide = rows_per_group >= 0 && rows_per_group <= 2 && wide_model(e->md);  // a default call runs the WIDE instance there
-    const int R = choose_R(e, tiles, P, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide);
+    const int R = choose_R(e, tiles, P, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide, true);
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
     const long long groups = (tiles + R - 1) / R;
     if (n_workgroups) *n_workgroups = (int)(groups * P);
@@ -672,7 +677,7 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
         slices = P;
     }
     const bool wide = wide_model(md) && call_lean;
-    const int R = choose_R(e, tiles, slices, 0, horizon, wide);
+    const int R = choose_R(e, tiles, slices, 0, horizon, wide, mode == HIPETS_MODE_FAST);
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("the model does not fit LDS");
     int cls = HIPETS_KERNEL_GENERIC;
     if (md.precision == HIPETS_PREC_BF16X3) {
@@ -787,7 +792,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             wide = lean_call(md, probe) && o->rows_per_group <= 2;
         }
         ra.wide_lds = wide ? 1 : 0;
-        const int R = choose_R(e, tiles, domains, o->rows_per_group, H, wide);
+        const int R = choose_R(e, tiles, domains, o->rows_per_group, H, wide, false);
         const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
@@ -901,7 +906,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
                         "the wide-output instance's: size member_schedule with hipets_fast_geometry(rows_per_group = -1) and pass its row-tile "
                         "count as opts->rows_per_group");
         ra.wide_lds = wide ? 1 : 0;
-        const int R = choose_R(e, tiles, P, o->rows_per_group, H, wide);
+        const int R = choose_R(e, tiles, P, o->rows_per_group, H, wide, true);
         const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
@@ -1056,7 +1061,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
             return fail("EXACT mode with per-row member maps needs opts.rows_per_member in [1, B] (padded member slots)");
         const int rpd = expectation ? B : (slots ? o->rows_per_member : B / domains);
         const long long tiles = (rpd + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, domains, o->rows_per_group, 1);
+        const int R = choose_R(e, tiles, domains, o->rows_per_group, 1, false, false);
         const size_t lds = lds_for(e, R, 1);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         ra.groups = (int)((tiles + R - 1) / R);
@@ -1077,7 +1082,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         if (launch_rollout(e, R, domains * ra.groups, lds, ra, st)) return 1;
     } else if (o->mode == HIPETS_MODE_FAST) {
         const long long tiles = (B + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, 1, o->rows_per_group, 1);
+        const int R = choose_R(e, tiles, 1, o->rows_per_group, 1, false, true);
         const size_t lds = lds_for(e, R, 1);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int nwg = (int)((tiles + R - 1) / R);
