@@ -204,9 +204,14 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
     const double a = 1.77 * (double)C / 13.0;  // the fixed part scales with the layer width like the units do
     int best = 1;
     double best_cost = 1e300;
+    // bf16x3 arithmetic exists in shape-specialised instances only: among the R that have one (if any has: else the launch reports it)
+    bool b3_only = false;
+    if (e->md.precision == HIPETS_PREC_BF16X3)
+        for (int R = 1; R <= kMaxR; ++R) b3_only = b3_only || b3_shape_exists(e->md, R);
     for (int R = 1; R <= kMaxR; ++R) {
         if (lds_for(e, R, horizon, wide) > e->lds_max) break;
         if (wide && R > 2) break;  // WIDE instances exist for R = 1, 2 (rollout_inst.inc)
+        if (b3_only && !b3_shape_exists(e->md, R)) continue;
         const long long groups = (tiles_total_per_slice + R - 1) / R;
         const long long nwg = groups * slices;
         const long long n = (nwg + e->num_cu - 1) / e->num_cu;  // workgroups the busiest CU serves
