@@ -220,7 +220,7 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         const double u_pair = (co == 2 && desync) ? (double)C * R / 4.0 : u;
         const long long full = n / co, rem = n % co;
         double cost = (double)full * (a + co * u_pair) + (rem ? a + (double)rem * u : 0.0);
-        if (!lean_shape_exists(e->md, R)) cost *= 1.08;
+        if (!lean_shape_exists(e->md, R, desync)) cost *= 1.08;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best = R;
@@ -690,7 +690,7 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
         cls = HIPETS_KERNEL_FUSED;
     } else if (wide) {
         cls = HIPETS_KERNEL_WIDE;
-    } else if (call_lean && !wide_model(md) && lean_shape_exists(md, R)) {
+    } else if (call_lean && !wide_model(md) && lean_shape_exists(md, R, mode == HIPETS_MODE_FAST)) {
         cls = HIPETS_KERNEL_FUSED;
     } else {
 #define HIPETS_CLASS_HID(HC) if (hid_static_call(md, probe, HC)) cls = HIPETS_KERNEL_HIDDEN_STATIC;

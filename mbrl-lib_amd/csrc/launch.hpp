@@ -56,6 +56,12 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS) \
     X(13, 1, HIPETS_REW_LEARNED, HIPETS_TERM_INVERTED_PENDULUM, HIPETS_OBS_NONE)
 #define HIPETS_LEAN_SHAPES_R4(X) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE)
+// Shapes with FAST instances ONLY (KSpec: termination functions over every state dim of a model wider than one column tile --
+// pets_hopper: obs 11 / act 3, learned reward, pop 350 x 20 -> R = 1; DEVICE-mode calls of these models run the hidden-static instance)
+#define HIPETS_LEAN_FAST_SHAPES_R1(X) X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
+#define HIPETS_LEAN_FAST_SHAPES_R2(X) X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
+#define HIPETS_LEAN_FAST_SHAPES_R3(X)
+#define HIPETS_LEAN_FAST_SHAPES_R4(X)
 
 // bf16x3 precision instances per R: X(hidden column tiles, output column tiles, reward fn, termination fn); no obs preprocessing
 #define HIPETS_B3_SHAPES_R1(X) X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE)
@@ -68,6 +74,7 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
 // tile 0 holds output columns 0..7)
 inline bool fused_term_ok(const ModelDev& md) {
     if (md.term_fn == HIPETS_TERM_INVERTED_PENDULUM && md.obs_dim > 4) return false;
+    if (md.term_fn == HIPETS_TERM_HOPPER) return md.reward_fn == HIPETS_REW_LEARNED;  // every lane judges its own dims (FAST instances, KSpec)
     if (md.reward_fn == HIPETS_REW_LEARNED && md.term_fn != HIPETS_TERM_NONE && md.obs_dim >= 8) return false;
     return true;
 }
@@ -80,7 +87,7 @@ inline bool lean_model(const ModelDev& md) {
 
 // is there a lean fp32 instance of this model's shape for R row tiles? (what the launcher of rollout_r<R>.hip will find; the cost
 // model prices a (shape, R) pair with an instance lower than one that runs the hidden-static or the generic kernel)
-inline bool lean_shape_exists(const ModelDev& md, const int R) {
+inline bool lean_shape_exists(const ModelDev& md, const int R, const bool fast = false) {
     if (!lean_model(md)) return false;
 #define HIPETS_HAS_SHAPE(HC, OC, RW, TM, OB) \
     if (md.hidC == HC && md.outC == OC && md.reward_fn == RW && md.term_fn == TM && md.obs_process == OB && md.ld == lean_ld(HC, OC)) return true;
@@ -89,6 +96,13 @@ inline bool lean_shape_exists(const ModelDev& md, const int R) {
         case 2: HIPETS_LEAN_SHAPES_R2(HIPETS_HAS_SHAPE) break;
         case 3: HIPETS_LEAN_SHAPES_R3(HIPETS_HAS_SHAPE) break;
         case 4: HIPETS_LEAN_SHAPES_R4(HIPETS_HAS_SHAPE) break;
+        default: break;
+    }
+    if (fast) switch (R) {
+        case 1: HIPETS_LEAN_FAST_SHAPES_R1(HIPETS_HAS_SHAPE) break;
+        case 2: HIPETS_LEAN_FAST_SHAPES_R2(HIPETS_HAS_SHAPE) break;
+        case 3: HIPETS_LEAN_FAST_SHAPES_R3(HIPETS_HAS_SHAPE) break;
+        case 4: HIPETS_LEAN_FAST_SHAPES_R4(HIPETS_HAS_SHAPE) break;
         default: break;
     }
 #undef HIPETS_HAS_SHAPE

@@ -1123,8 +1123,16 @@ struct KSpec {
     // termination functions that test EVERY state dim (inverted_pendulum: isfinite(next_obs).all(), termination_fns.py:47-55) are fused for
     // models with obs_dim <= 4 only -- then dims 0..3 ARE every dim (launch.hpp fused_term_ok checks the model)
     static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS || REW_ == HIPETS_REW_LEARNED) &&
-                            (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID || TERM_ == HIPETS_TERM_INVERTED_PENDULUM)),
+                            (TERM_ == HIPETS_TERM_NONE || TERM_ == HIPETS_TERM_CARTPOLE || TERM_ == HIPETS_TERM_HUMANOID || TERM_ == HIPETS_TERM_INVERTED_PENDULUM ||
+                             TERM_ == HIPETS_TERM_HOPPER)),
                   "fused tail: the reward / termination lane sees dims 0..3 of its row");
+    // hopper (termination_fns.py:12-26) tests EVERY state dim of a model whose dims span several column tiles, i.e. several waves: every
+    // tail lane judges its own two dims and raises a per-row flag in LDS; the flag of step t is complete at the barrier that ends the
+    // step and is folded into the row's `terminated` by the tail of step t + 1 -- which is when it first matters (model_env.py:186-188:
+    // the reward of the terminating step itself still counts).  The row must still be HERE then: FAST instances only (in the persistent
+    // DEVICE form it has moved to another workgroup, which would need the flag through the hand-over table); learned rewards only.
+    static_assert(!FUSE || TERM_ != HIPETS_TERM_HOPPER || (REW_ == HIPETS_REW_LEARNED && KMODE_ == HIPETS_MODE_FAST && !WIDE),
+                  "fused tail with an all-dims termination function: FAST instances with a learned reward");
     // learned rewards (round 4): the reward is the sampled LAST output column.  Without a termination function (pets_pusher / pets_reacher /
     // pets_mppi_halfcheetah) the lane that holds that column keeps the row's running total and needs no state dim at all; with one
     // (pets_inv_pendulum) the lane with dims 0, 1 keeps it and fetches the reward from the column's lane of the SAME accumulator, i.e. the
@@ -2117,7 +2125,14 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 // lane that holds output column obs_dim, whose sampled value IS the reward (one_dim_tr_model.py:287).  (A wave can hold
                 // several such units -- one per row tile when the output layer has >= 4 column tiles -- hence here, per unit.)
                 constexpr bool kLearnedRew = S::REW == HIPETS_REW_LEARNED;
-                constexpr bool kRewLane = kLearnedRew && S::TERM == HIPETS_TERM_NONE;  // the reward column's lane keeps the total (else: the lane with dims 0, 1)
+                constexpr bool kAllDims = S::TERM == HIPETS_TERM_HOPPER;  // every lane judges its own dims; flags through LDS, folded in one step later (KSpec)
+                constexpr bool kRewLane = kLearnedRew && (S::TERM == HIPETS_TERM_NONE || kAllDims);  // the reward column's lane keeps the total (else: the lane with dims 0, 1)
+                if constexpr (kAllDims) {  // hopper: all dims finite, |dims 1..| < 100, height (dim 0) > 0.7, |angle (dim 1)| < 0.2
+                    bool bad = false;
+                    if (okA) bad = !isfinite(vA) || (d0 >= 1 ? !(fabsf(vA) < 100.0f) : !(vA > 0.7f));
+                    if (okB) bad = bad || !isfinite(vB) || !(fabsf(vB) < 100.0f) || (d0 == 0 && !(fabsf(vB) < 0.2f));
+                    if (bad) sm.pend[(t & 1) * ROWS + s] = 1;  // (every writer stores the same value; read after this step's barrier)
+                }
                 const int c_rew = kRewLane ? (md.obs_dim >> 3) : 0, g_rew = kRewLane ? ((md.obs_dim & 7) >> 1) : 0;
                 if (c == c_rew) {  // wave-uniform
                     float st[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2155,7 +2170,14 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         float rwd;
                         if constexpr (kLearnedRew) rwd = lrew;
                         else rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
-                        const bool done = term_eval(st, 4, S::TERM);
+                        bool done = false;
+                        if constexpr (kAllDims) {  // `terminated` up to and including step t - 1: that step's flag is complete since its barrier
+                            int* const flag = sm.pend + ((t & 1) ^ 1) * ROWS + s;
+                            trm = trm | (t > ra.t_begin ? *flag : 0);
+                            *flag = 0;  // (raised again in step t + 1 at the earliest: two barriers away)
+                        } else {
+                            done = term_eval(st, 4, S::TERM);
+                        }
                         if (trm) rwd = 0.f;
                         trm = trm | (done ? 1 : 0);
                         tot += rwd;

@@ -38,6 +38,8 @@ WORKLOADS = {
     # conf/overrides/pets_inv_pendulum.yaml: learned reward + the inverted_pendulum termination function (every state dim)
     "stock_inv_pendulum": (4, 1, dict(ensemble_size=7, elite=[0, 2, 3, 5, 6], learned_rewards=True, reward=None, termination="inverted_pendulum"),
                            480, 20, 45, 0.078, 0.134484),
+    # conf/overrides/pets_hopper.yaml: learned reward + the hopper termination function (eleven state dims): fused in FAST mode only
+    "stock_hopper": (11, 3, dict(ensemble_size=7, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None, termination="hopper"), 350, 20, 30, 0.1, 0.1),
 }
 
 
@@ -84,6 +86,8 @@ def main():
         eng.set_model(spec)
         acts = (torch.rand(pop, H, act, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
         s0 = (np.random.default_rng(0).standard_normal(obs) * 0.1).astype(np.float32)
+        if om.termination == "hopper":
+            s0[0] = 1.25  # a standing hopper (termination_fns.py:12-26)
         fl = flops(om)
         nwg, r = eng.fast_geometry(pop, P, H, 0)
         res = {"flop_per_candidate_step": fl, "candidate_steps_per_rollout": pop * P * H, "fast_geometry": {"workgroups": nwg, "row_tiles": r},

@@ -33,7 +33,12 @@ COMBOS = [
     ("cartpole_pets_leaky", 4, 1, dict(reward="cartpole_pets", termination="cartpole", obs_process="cartpole_pets", activation="leaky_relu"), {}),
     ("humanoid_tanh", 9, 3, dict(termination="humanoid", activation="tanh"), {0: 1.05}),
     ("cartpole", 4, 1, dict(reward="cartpole", termination="cartpole"), {0: 2.3}),
+    # the all-dims termination functions INSIDE the fused tail (hid 200, SiLU, learned reward: the pets_hopper and pets_inv_pendulum
+    # instances -- hopper's per-lane judgement with the flag folded in one step later, FAST mode; inverted_pendulum's four dims on one lane)
+    ("hopper_learned_fused", 11, 3, dict(termination="hopper", learned_rewards=True, reward=None, hid=200), {0: 0.76, 1: 0.0}),
+    ("inv_pendulum_learned_fused", 4, 1, dict(termination="inverted_pendulum", learned_rewards=True, reward=None, hid=200), {1: 0.16}),
 ]
+FUSED_AT = {"hopper_learned_fused": (0, ("fast",)), "inv_pendulum_learned_fused": (3, ("fast", "device"))}  # forced row tiles, modes that run the fused instance
 IDS = [c[0] for c in COMBOS]
 
 
@@ -59,15 +64,16 @@ def threshold_margin(name, nobs):
 
 def make(combo, seed=0):
     name, obs, act, mkw, s0_fix = combo
-    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=40, seed=seed + 3, **mkw)
+    mkw = dict(mkw)
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=mkw.pop("hid", 40), seed=seed + 3, **mkw)
     s0 = (np.random.default_rng(seed).standard_normal(obs) * 0.05).astype(np.float32)
     for d, v in s0_fix.items():
         s0[d] = v
     return om, s0
 
 
-def fast_members(engine, pop, P, H, seed, sid, fixed=False):
-    nwg, r = engine.fast_geometry(pop, P, H)
+def fast_members(engine, pop, P, H, seed, sid, fixed=False, rows_per_group=0):
+    nwg, r = engine.fast_geometry(pop, P, H, rows_per_group)
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     rows = torch.arange(pop * P)
     wg = ((rows // P) // (16 * r)) * P + rows % P
@@ -98,17 +104,21 @@ def test_rollouts_with_terminating_and_non_finite_rows(engine, combo, mode):
     actions[3, 2:] = float("nan")  # candidate 3 from step 2 on, candidate 17 from step 5 on: their rows go non-finite
     actions[17, 5:] = float("nan")
     seed, sid = 321, 4
+    rpg, fused_modes = FUSED_AT.get(name, (0, ()))
+    if mode in fused_modes:  # the case exists to exercise the fused instance: make sure it is the one that runs
+        cls, r = engine.kernel_class(pop, P, H, mode)
+        assert cls == "fused" or rpg, (cls, r)
     if mode == "exact":
         perms = torch.stack([torch.randperm(B, generator=g) for _ in range(H)])
         eps = torch.randn(H, B, om.out_size, generator=g)
         out = engine.rollout(actions.to(DEV), s0, P, mode="exact", perms=perms.to(DEV), eps=eps.to(DEV))
         kw = dict(perms=perms, eps=eps)
     elif mode == "device":
-        out = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid)
+        out = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid, rows_per_group=rpg)
         kw = dict(perms=engine.device_perms(H, B, seed, sid).cpu(), eps=engine.fast_normals(H, B, seed, sid).cpu())
     else:
-        out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
-        kw = dict(members=fast_members(engine, pop, P, H, seed, sid), eps=engine.fast_normals(H, B, seed, sid).cpu())
+        out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid, rows_per_group=rpg)
+        kw = dict(members=fast_members(engine, pop, P, H, seed, sid, rows_per_group=rpg), eps=engine.fast_normals(H, B, seed, sid).cpu())
     trace = {}
     ref = po.rollout(om, actions, s0, P, trace=trace, **kw)
     nobs = torch.stack(trace["next_obs"])      # [H, B, obs]
