@@ -69,6 +69,28 @@ def synthetic_spec(device, precision="f32", obs=OBS, act=ACT, ensemble=ENSEMBLE,
         obs_process=obs_process, reward=None if learned_rewards else reward, termination=termination, precision=precision)
 
 
+def synthetic_planet_spec(device, latent=30, action=6, belief=200, hidden=200, seed=0):
+    """Random-init PlaNet heads with the reference's initialisers (mbrl/models/planet.py:20-30: orthogonal GRU W_hh, Xavier-uniform
+    everything else) at conf/dynamics_model/planet.yaml's sizes, built on the product side (no oracle): what
+    PlaNetModel.sample (planet.py:531-581) reads."""
+    import hipets
+
+    g = torch.Generator().manual_seed(seed)
+
+    def xavier(out_f, in_f):
+        return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * float(np.sqrt(6.0 / (in_f + out_f)))).to(device)
+
+    def bias(n):
+        return ((torch.rand(n, generator=g) * 2 - 1) * 0.05).to(device)
+
+    q, _ = torch.linalg.qr(torch.randn(3 * belief, belief, generator=g))
+    return hipets.PlaNetSpec(
+        w_embed=xavier(belief, latent + action), b_embed=bias(belief), w_ih=xavier(3 * belief, belief), b_ih=bias(3 * belief),
+        w_hh=q.contiguous().to(device), b_hh=bias(3 * belief), w_prior1=xavier(hidden, belief), b_prior1=bias(hidden),
+        w_prior2=xavier(2 * latent, hidden), b_prior2=bias(2 * latent), w_rew1=xavier(hidden, belief + latent), b_rew1=bias(hidden),
+        w_rew2=xavier(hidden, hidden), b_rew2=bias(hidden), w_rew3=xavier(1, hidden), b_rew3=bias(1), min_std=0.1)
+
+
 # Other workloads on the same line (never `value`): the configurations the reference ships as its defaults, and the remaining
 # BASELINE.json configs (parity-test cases: tests/test_gpu_plans_full_size.py pins each at this size).  Each: model kwargs of
 # synthetic_spec, optimizer kind + its stock parameters, P, H.
@@ -118,7 +140,8 @@ def _cpu_model():
 
 
 def cpu_baseline(budget_s=30.0):
-    """The reference's algorithm on this box's host cores: the oracle -- a torch-CPU restatement
+    """kind "reference" where /root/reference is mounted (the reference's own classes), else kind "port":
+    the reference's algorithm on this box's host cores: the oracle -- a torch-CPU restatement
     that is BITWISE equal to mbrl-lib's TrajectoryOptimizerAgent + CEMOptimizer + ModelEnv at this exact size
     (tests/test_oracle_full_size.py pins it against a golden recorded from the unmodified reference) -- timed on FULL
     cfg2 plans: one warm-up plan, then >= 5 timed plans (CEM loop included), min and median reported.  Checker code, used
@@ -164,6 +187,35 @@ def cpu_baseline(budget_s=30.0):
         if len(times) >= 5 and time.perf_counter() - t_start > budget_s:
             break
     cs = ITERS * POP * PARTICLES * HORIZON
+    port = {"value": cs / min(times), "unit": "candidate-steps/s", "ms_per_plan_min": 1e3 * min(times), "plans_timed": len(times)}
+    # Where the reference itself is mounted (the build container; never the GPU box), its OWN classes are timed -- the unmodified
+    # mbrl.planning.CEMOptimizer + mbrl.models.ModelEnv.evaluate_action_sequences (trajectory_opt.py:142-188, model_env.py:145-191)
+    # imported through oracle/ref_bridge.py -- and reported as kind "reference" with the port beside it.
+    try:
+        from oracle import ref_bridge
+
+        have_ref = ref_bridge.reference_available()
+    except Exception:
+        have_ref = False
+    if have_ref:
+        mbrl = ref_bridge.import_reference()
+        me, _, _ = ref_bridge.build_reference_model_env(om, OBS, ACT, generator=torch.Generator().manual_seed(0))
+        ref_opt = mbrl.planning.CEMOptimizer(ITERS, ELITE_RATIO, POP, lb.tolist(), ub.tolist(), ALPHA, "cpu", return_mean_elites=True)
+
+        def ref_plan():
+            t0 = time.perf_counter()
+            ref_opt.optimize(lambda a: me.evaluate_action_sequences(a, initial_state=s0, num_particles=PARTICLES), x0=torch.zeros(HORIZON, ACT))
+            return time.perf_counter() - t0
+
+        ref_plan()
+        rtimes = [ref_plan() for _ in range(max(5, len(times)))]
+        return {"value": cs / min(rtimes), "unit": "candidate-steps/s", "cores": best_threads, "kind": "reference",
+                "value_median": cs / statistics.median(rtimes), "ms_per_plan_min": 1e3 * min(rtimes), "ms_per_plan_median": 1e3 * statistics.median(rtimes),
+                "plans_timed": len(rtimes), "port_beside_it": port, "port_over_reference": port["value"] / (cs / min(rtimes)),
+                "sample": f"{len(rtimes)} full cfg2 plans of the UNMODIFIED reference classes (mbrl.planning.CEMOptimizer + ModelEnv.evaluate_action_sequences, "
+                          f"{cs} candidate-steps each) after 1 warm-up plan, on {best_threads} threads (calibrated on the port); the bitwise port timed the same way beside it",
+                "host": {"nproc": os.cpu_count(), "usable_cores": usable, "cpu_model": _cpu_model(), "torch": torch.__version__},
+                "plans_per_s": 1.0 / min(rtimes)}
     return {"value": cs / min(times), "unit": "candidate-steps/s", "cores": best_threads, "kind": "port",
             "value_median": cs / statistics.median(times), "ms_per_plan_min": 1e3 * min(times),
             "ms_per_plan_median": 1e3 * statistics.median(times), "plans_timed": len(times),
@@ -216,7 +268,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-batched", dest="no_extras", action="store_true", help="skip the extra blocks (other mode, batched planning, agent.act)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="print the cpu_baseline object alone (needs no GPU) and exit")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.cpu_budget)}))
+        return
 
     import hipets
     from hipets import dist as hdist
@@ -552,6 +608,100 @@ def main():
             others[name] = {"optimizer": w["optimizer"], args.mode: measure_workload(w, args.mode, 3 if w["pop"] >= 1000 else max(4, args.steps // 4))}
         others["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"][other] = measure_workload(OTHER_CONFIGS["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"], other, 3)
         extras["other_configs"] = others
+        engine.set_model(spec)
+
+    if world == 1 and not args.no_extras:
+        # SURVEY.md 8(f) rows with parity and, until round 5, no driver-run number.
+        # f2 -- ModelEnv.step at MBPO's shape (mbrl/algorithms/mbpo.py:30-63 rollout_model_and_populate_sac_buffer: ONE model
+        # transition per call for a batch of rows; conf/overrides/mbpo_halfcheetah.yaml:13-15: 400 x 250 = 100 000 rows; obs 17 /
+        # act 6, conf/dynamics_model/gaussian_mlp_ensemble.yaml: 7 members / 5 elites): hipets_step, both randomness modes.
+        spec_s = synthetic_spec(device, ensemble=7, elite=[0, 1, 2, 3, 4])
+        engine.set_model(spec_s)
+        B_s = 100_000
+        g_s = torch.Generator().manual_seed(3)
+        obs_b = (torch.randn(B_s, OBS, generator=g_s) * 0.1).to(device)
+        act_b = (torch.rand(B_s, ACT, generator=g_s) * 2 - 1).to(device)
+        blk_s = {"workload": f"hipets_step (ModelEnv.step, mbrl/models/model_env.py:87-140) on {B_s} rows per call, obs {OBS} act {ACT}, 7 members / 5 elites "
+                             "(MBPO's model rollouts: mbrl/algorithms/mbpo.py:30-63, conf/overrides/mbpo_halfcheetah.yaml:13-15), next_obs / rewards / dones "
+                             "written to HBM every call"}
+        fl_s = spec_s.flops_per_candidate_step()
+        for m_ in ("device", "fast"):
+            t_w, i_w = time.perf_counter(), 0
+            while i_w < 3 or time.perf_counter() - t_w < 0.25:
+                engine.step(obs_b, act_b, mode=m_, seed=1, stream_id=i_w)
+                torch.cuda.synchronize()
+                i_w += 1
+            n_s = max(10, args.steps)
+            engine.timing_enable(1)
+            engine.timing_read(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_s):
+                engine.step(obs_b, act_b, mode=m_, seed=1, stream_id=i)
+            torch.cuda.synchronize()
+            el_s = (time.perf_counter() - t0) / n_s
+            n_l, k_ms = engine.timing_read(reset=True)
+            engine.timing_enable(False)
+            avg_ms = k_ms / max(n_l, 1)
+            ach = B_s * fl_s / (avg_ms * 1e-3) / 1e12 if n_l else None
+            blk_s[m_] = {"value": B_s / el_s, "unit": "rows (model transitions)/s", "ms_per_call": 1e3 * el_s, "calls_timed": n_s,
+                         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS if ach else None,
+                                      "kernel": "hipets::rollout_kernel (one step per launch)", "launches_per_call": n_l / n_s, "avg_launch_ms": avg_ms,
+                                      "flops_per_candidate_step": fl_s, "algorithmic_flops_per_launch": B_s * fl_s,
+                                      "algorithmic_hbm_bytes_per_call": 4 * B_s * (OBS + ACT + OBS + 1) + B_s}}
+        extras["model_env_step"] = blk_s
+        # f4 -- the PlaNet latent planner (mbrl/models/planet.py:531-581 through ModelEnv.evaluate_action_sequences and the CEM loop,
+        # conf/overrides/planet_cheetah_run.yaml:29-35: clipped-normal CEM, pop 1000, H 12, 10 iterations, alpha 0; conf/dynamics_model/
+        # planet.yaml sizes: latent 30, belief 200, hidden 200): ONE library call per plan (hipets_plan_planet_cem)
+        spec_p = synthetic_planet_spec(device)
+        engine.planet_set_model(spec_p)
+        fn_p = hipets.make_eval_fn(spec_p, 1, engine=engine, seed=0)
+        fn_p.set_state(torch.zeros(1, 30), torch.zeros(1, 200))
+        P_ITERS, P_POP, P_H = 10, 1000, 12
+        opt_p = hipets.CEMOptimizer(P_ITERS, 0.1, P_POP, [[-1.0] * ACT] * P_H, [[1.0] * ACT] * P_H, 0.0, device, return_mean_elites=True,
+                                    clipped_normal=True, seed=1)
+        obj_p = _BoundObjective(fn_p, np.zeros((3, 64, 64), np.float32))
+        x0_p = torch.zeros(P_H, ACT, device=device)
+        plan_p = lambda: opt_p.optimize(obj_p, x0=x0_p)  # noqa: E731
+        t_w, i_w = time.perf_counter(), 0
+        while i_w < 3 or time.perf_counter() - t_w < 0.25:
+            plan_p()
+            torch.cuda.synchronize()
+            i_w += 1
+        n_p = max(5, args.steps // 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_p):
+            sol_p = plan_p()
+        torch.cuda.synchronize()
+        el_p = (time.perf_counter() - t0) / n_p
+        assert torch.isfinite(sol_p).all()
+        # the rollout kernel alone: one launch per CEM iteration (pop x H candidate-steps), torch events around a burst of launches on
+        # the current stream (the library launches on it)
+        acts_p = (torch.rand(P_POP, P_H, ACT, generator=g_s) * 2 - 1).to(device)
+        l0_p, b0_p = torch.zeros(30, device=device), torch.zeros(200, device=device)
+        for _ in range(5):
+            engine.planet_rollout(acts_p, l0_p, b0_p, 1, seed=1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_r = 20
+        ev0.record()
+        for _ in range(n_r):
+            engine.planet_rollout(acts_p, l0_p, b0_p, 1, seed=1)
+        ev1.record()
+        torch.cuda.synchronize()
+        roll_ms = ev0.elapsed_time(ev1) / n_r
+        fl_p = spec_p.flops_per_candidate_step()
+        cs_p = P_ITERS * P_POP * P_H
+        ach_p = P_POP * P_H * fl_p / (roll_ms * 1e-3) / 1e12
+        extras["planet"] = {"workload": "PlaNet latent planner, conf/overrides/planet_cheetah_run.yaml:29-35 (clipped-normal CEM, pop 1000, H 12, 10 iterations, alpha 0) on "
+                                        "conf/dynamics_model/planet.yaml sizes (latent 30, belief 200, hidden 200, action 6), one particle; one hipets_plan_planet_cem call per plan",
+                            "ms_per_plan": 1e3 * el_p, "value": cs_p / el_p, "unit": "candidate-steps/s", "candidate_steps_per_plan": cs_p, "plans_timed": n_p,
+                            "roofline": {"bound": "mfma", "achieved": ach_p, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach_p / PEAK_FP32_TFLOPS,
+                                         "kernel": "hipets::planet_rollout_kernel", "avg_launch_ms": roll_ms, "flops_per_candidate_step": fl_p,
+                                         "algorithmic_flops_per_launch": P_POP * P_H * fl_p,
+                                         "launches_timed": f"{n_r} back-to-back hipets_planet_rollout launches (pop {P_POP} x H {P_H}) between two events on the launch stream, "
+                                                           "including the ~2 us launch gap each"},
+                            "plan_frac_of_fp32_peak_end_to_end": cs_p * fl_p / el_p / 1e12 / PEAK_FP32_TFLOPS}
         engine.set_model(spec)
 
     cand_steps_per_plan = ITERS * pop * PARTICLES * HORIZON

@@ -240,7 +240,8 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
  *     per-step launches: re-run the call (hipets.planning does exactly this).  A caller that never asks gets the report as an
  *     error from its NEXT rollout / plan call instead.
  * The persistent form assumes what the reference's deployment gives it -- one planning process per GPU; on = 0 forces per-step
- * launches (also: env HIPETS_NO_PERSISTENT=1).                                                                             */
+ * launches (also: env HIPETS_NO_PERSISTENT=1).  Env HIPETS_MAX_WORKGROUPS=n caps the workgroups of a persistent launch at n (the
+ * rest of the batch is served in turns, as when the chip is the limit): processes that share a GPU can leave each other room.   */
 int hipets_set_persistent(hipets_engine* e, int32_t on);
 int hipets_set_handover_timeout(hipets_engine* e, double seconds);
 int hipets_check_async_error(hipets_engine* e, int32_t* timed_out);

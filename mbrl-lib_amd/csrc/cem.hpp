@@ -129,9 +129,12 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     __syncthreads();
     // order: "a before b" iff (key_a > key_b) or (equal and idx_a < idx_b)
     if (elite_in) {  // the caller's elites, in the caller's order
-        const float top_key = key[elite_in[0]];
+        // (indices are clamped into [0, pop): the Python wrapper rejects out-of-range ones with a ValueError -- Engine.cem_refit -- and a
+        // raw-ABI caller that passes garbage gets a wrong refit, never an out-of-bounds LDS / global read)
+        auto in_range = [&](const int e) { return e < 0 ? 0 : (e >= p.pop ? p.pop - 1 : e); };
+        const float top_key = key[in_range(elite_in[0])];
         __syncthreads();
-        for (int k = tid; k < p.K; k += kRefitThreads) idx[k] = elite_in[k];
+        for (int k = tid; k < p.K; k += kRefitThreads) idx[k] = in_range(elite_in[k]);
         if (tid == 0) key[0] = top_key;  // key[] is only consulted at position 0 from here on
         __syncthreads();
     } else if (p.pop <= kRankSortMax) {

@@ -2523,6 +2523,14 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     }
 
     // ---- write back -------------------------------------------------------------------------------
+    if constexpr (kFuse && S::TERM == HIPETS_TERM_HOPPER) {
+        // the fused all-dims termination folds step t's per-row flag into `terminated` one step later (tail_unit): the LAST step's
+        // flag is still pending here.  It cannot change a return (model_env.py:186-188: the terminating step's reward counts), but
+        // sm.term is what a write-back would publish, so it is completed before anything reads it (complete since the step's barrier;
+        // the launcher admits these instances for whole-horizon launches only, rollout_inst.inc)
+        if (ra.t_end > ra.t_begin)
+            for (int s = tid; s < ROWS; s += kThreads) sm.term[s] |= sm.pend[((ra.t_end - 1) & 1) * ROWS + s];
+    }
     for (int s = tid; s < ROWS; s += kThreads) {
         const int rid = sm.rowid[s];
         if (rid < 0 || persist) continue;  // persistent form: written in the last step's reward phase

@@ -160,9 +160,11 @@ ERR_NONE, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_TIMEOUT = 0, 1, 2, 3
 
 class HipetsError(RuntimeError):
     """A failed libhipets call.  ``kind`` = hipets_last_error_kind(): ERR_INVALID_ARGUMENT (the library refused the arguments: the
-    same on every rank that passed them), ERR_RUNTIME (a HIP / RCCL call, an allocation or a launch failed), ERR_TIMEOUT."""
+    same on every rank that passed them), ERR_RUNTIME (a HIP / RCCL call, an allocation or a launch failed), ERR_TIMEOUT.  An error
+    raised on the Python side without a kind (a missing library, an engine without a model) counts as a runtime failure: only the C
+    library's own verdict marks an error as a deterministic rejection of the arguments (hipets.dist.run_sharded relies on that)."""
 
-    def __init__(self, message="", kind: int = ERR_INVALID_ARGUMENT):
+    def __init__(self, message="", kind: int = ERR_RUNTIME):
         super().__init__(message)
         self.kind = kind
 

@@ -123,7 +123,7 @@ def run_sharded(engine, sharded_call: Callable, single_call: Callable, group=Non
     from ._lib import ERR_INVALID_ARGUMENT, HipetsError
 
     if engine.comm_world > 1:
-        code, reason, result, error = _OK, None, None, None
+        code, reason, result, error, foreign = _OK, None, None, None, None
         try:
             result = sharded_call()
             engine.synchronize()
@@ -131,12 +131,18 @@ def run_sharded(engine, sharded_call: Callable, single_call: Callable, group=Non
                 code, reason = _RUNTIME_FAILURE, "a persistent DEVICE-mode rollout timed out"
         except HipetsError as exc:
             error, reason = exc, str(exc)
-            code = _REJECTED if getattr(exc, "kind", ERR_INVALID_ARGUMENT) == ERR_INVALID_ARGUMENT else _RUNTIME_FAILURE
+            code = _REJECTED if exc.kind == ERR_INVALID_ARGUMENT else _RUNTIME_FAILURE
+        except Exception as exc:  # not the library's: a torch RuntimeError out of engine.synchronize() (a HIP fault on THIS rank), ...
+            # the peers are (or will be) waiting in the agreement below: take part in it as a runtime failure so that they fall
+            # back instead of blocking in the all-reduce, THEN let the exception out -- this rank's device state is unknown
+            foreign, reason, code = exc, repr(exc), _RUNTIME_FAILURE
         worst = _worst_status(code, group)
+        if foreign is not None:
+            raise foreign
         if worst == _OK:
             return result, False
         if worst == _REJECTED:
-            raise error if code == _REJECTED else HipetsError("a peer rank rejected the arguments of the sharded plan")
+            raise error if code == _REJECTED else HipetsError("a peer rank rejected the arguments of the sharded plan", ERR_INVALID_ARGUMENT)
         warnings.warn(f"hipets: sharded plan failed on rank {engine.comm_rank} or a peer ({reason or 'peer failure'}); "
                       f"falling back to a single-GPU plan on every rank")
         try:

@@ -390,6 +390,10 @@ class Engine:
             _check_dev(elite_idx, torch.int32, dev, "elite_idx", (p.elite_num,))
         if elites is not None:
             _check_dev(elites, torch.int32, dev, "elites", (p.elite_num,))
+            # (this path follows a host-side torch.topk, i.e. it has synchronised with the host already: the range check is free)
+            lo, hi = int(elites.min()), int(elites.max())
+            if lo < 0 or hi >= p.population_size:
+                raise ValueError(f"elites must index the population [0, {p.population_size}): got {lo} .. {hi}")
             with torch.cuda.device(dev):
                 _lib.check(self._lib.hipets_cem_refit_elites(self._h, C.byref(p), _ptr(values), _ptr(population), _ptr(elites), _ptr(mu),
                                                              _ptr(dispersion), _ptr(best_value), _ptr(best_solution), _stream(dev)))

@@ -46,6 +46,7 @@ def pytest_sessionfinish(session, exitstatus):
 
         oracle_cache.flush_all()
         if oracle_cache.stats["hits"] or oracle_cache.stats["misses"]:
-            print(f"\n[oracle_cache] hits {oracle_cache.stats['hits']}, misses {oracle_cache.stats['misses']}")
+            print(f"\n[oracle_cache] hits {oracle_cache.stats['hits']}, misses {oracle_cache.stats['misses']}, "
+                  f"recomputed and compared with the stored entry {oracle_cache.stats.get('verified', 0)}")
     except Exception as exc:  # never fail a run over the memo
         print(f"[oracle_cache] {exc}")

@@ -123,6 +123,28 @@ def test_sharded_plan_falls_back_to_a_single_gpu_plan_when_rccl_fails():
         plan, fell_back = hdist.plan_cem_sharded(eng, None, None, None, None, None, 20, seed=1, plan_id=2)
     assert plan == ("single-gpu plan", 1, 2) and fell_back and eng.destroyed
 
+    # round-4 advice: an exception that is NOT the library's (a torch RuntimeError out of the stream sync: a HIP fault on this rank)
+    # must still reach the ranks' agreement -- as a runtime failure, so the peers fall back instead of blocking in the all-reduce --
+    # and then leave this rank as what it is; an error raised on the Python side without a kind is a runtime failure, not a rejection
+    agreed = []
+
+    class FaultingEngine(FakeEngine):
+        def plan_cem_sharded(self, *a, **k):
+            return "enqueued"
+
+        def synchronize(self):
+            raise RuntimeError("HIP error: an illegal memory access was encountered")
+
+    orig = hdist._worst_status
+    hdist._worst_status = lambda code, group=None: (agreed.append(code), orig(code, group))[1]
+    try:
+        with pytest.raises(RuntimeError, match="illegal memory access"):
+            hdist.plan_cem_sharded(FaultingEngine(""), None, None, None, None, None, 20)
+    finally:
+        hdist._worst_status = orig
+    assert agreed == [hdist._RUNTIME_FAILURE]
+    assert hipets.HipetsError("Engine.set_model() has not been called").kind == hipets.ERR_RUNTIME
+
 
 def test_failed_sharded_mppi_and_icem_attempts_are_undone_before_the_single_gpu_plan():
     """MPPI's persistent mean and iCEM's persistent elites are modified IN PLACE by a plan (trajectory_opt.py:238-311 self.mean,

@@ -42,7 +42,8 @@ def test_device_mode_replayed_through_oracle(engine, case):
         assert tuple(perms.shape) == ((pop * P,) if om.propagation == "fixed_model" else (H, pop * P))
     # (eps = the library's Philox normals of (seed, stream), exported only when the oracle has to run: tests/oracle_cache.py)
     ref = oc.cached("rollout_sizes", ["device", *oc.model_parts(om), actions, s0, P, perms, ("philox", seed, sid)],
-                    lambda: po.rollout(om, actions, s0, P, perms=perms, eps=None if om.deterministic else engine.fast_normals(H, pop * P, seed, sid).cpu()))
+                    lambda: po.rollout(om, actions, s0, P, perms=perms, eps=None if om.deterministic else engine.fast_normals(H, pop * P, seed, sid).cpu()),
+                    verify=case is DEVICE_SIZES[0])  # cfg2 at full size: never served from the memo alone
     assert_returns_close(out, ref)
     # determinism and seed sensitivity
     again = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=seed, stream_id=sid)

@@ -103,6 +103,11 @@ SIZES = [
     # pets_inv_pendulum (conf/overrides/pets_inv_pendulum.yaml: obs 4 / act 1, learned reward + the inverted_pendulum termination
     # function -- isfinite over every state dim, termination_fns.py:47-55 --, pop 480 x 20 particles, H 45)
     (4, 1, 480, 20, 45, dict(ensemble_size=7, hid=200, elite=[0, 2, 3, 5, 6], learned_rewards=True, reward=None, termination="inverted_pendulum")),
+    # pets_hopper (conf/overrides/pets_hopper.yaml: obs 11 / act 3, learned reward + the hopper termination function over all eleven
+    # dims, termination_fns.py:12-26; pop 350 x 20 particles, H 30) and pets_reacher (pets_reacher.yaml: obs 17 / act 7, learned reward,
+    # no_delta_list [0], pop 350 x 20, H 15) at full size (round 5: until then compared with the generic kernel only at this size)
+    (11, 3, 350, 20, 30, dict(ensemble_size=7, hid=200, elite=[0, 1, 3, 4, 6], learned_rewards=True, reward=None, termination="hopper")),
+    (17, 7, 350, 20, 15, dict(ensemble_size=7, hid=200, elite=[0, 1, 3, 4, 6], no_delta_list=[0], learned_rewards=True, reward=None)),
 ]
 # in-kernel randomness replays (FAST / DEVICE): everything but the expectation-propagation f32-normaliser case in FAST
 FAST_SIZES = SIZES[:9] + SIZES[10:]
@@ -115,7 +120,8 @@ def test_exact_mode_matches_oracle(engine, case):
     om, actions, s0, perms, eps = _random_case(obs, act, pop, P, H, **mkw)
     engine.set_model(to_spec(om, obs, act))
     # (every input derives from seeds on the CPU: the oracle's answer is memoised under their digest, tests/oracle_cache.py)
-    ref = oc.cached("rollout_sizes", ["exact", *oc.model_parts(om), actions, s0, P, perms, eps], lambda: po.rollout(om, actions, s0, P, perms=perms, eps=eps))
+    ref = oc.cached("rollout_sizes", ["exact", *oc.model_parts(om), actions, s0, P, perms, eps], lambda: po.rollout(om, actions, s0, P, perms=perms, eps=eps),
+                    verify=case is SIZES[0])  # cfg2 at full size: the oracle always runs and the stored entry must equal its answer
     out = engine.rollout(actions.to(DEV), s0, P, mode="exact", perms=None if perms is None else perms.to(DEV),
                          eps=None if eps is None else eps.to(DEV))
     assert_returns_close(out, ref)
@@ -137,7 +143,8 @@ def test_fast_mode_replayed_through_oracle(engine, case):
     members = torch.stack([sched[0 if om.propagation == "fixed_model" else t][wg].long() for t in range(H)])
     # eps = the library's Philox normals of (seed, stream): a function of the counters, exported only when the oracle has to run
     ref = oc.cached("rollout_sizes", ["fast", *oc.model_parts(om), actions, s0, P, members, ("philox", seed, sid)],
-                    lambda: po.rollout(om, actions, s0, P, members=members, eps=engine.fast_normals(H, pop * P, seed, sid).cpu()))
+                    lambda: po.rollout(om, actions, s0, P, members=members, eps=engine.fast_normals(H, pop * P, seed, sid).cpu()),
+                    verify=case is SIZES[0])
     assert_returns_close(out, ref)
     # the schedule is balanced: every member slot gets floor/ceil(nwg / M) workgroups at every step
     M = len(om.active_members)

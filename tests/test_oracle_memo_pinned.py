@@ -1,0 +1,109 @@
+"""The oracle memo (tests/golden/oracle_cache/rollout_sizes.npz) re-derived WITHOUT a GPU.
+
+The full-size GPU parity tests (tests/test_gpu_rollout.py, test_gpu_device_mode.py) compare the HIP rollout with the oracle's
+answer for the same seeded inputs, and since round 4 they read that answer from a memo keyed by the exact input bytes
+(tests/oracle_cache.py).  This file closes the link "oracle pinned to the reference -> GPU compared with the oracle": every entry of
+the rollout memo is recomputed here, on the CPU, with the CURRENT oracle, and must (1) exist under the key the GPU test will look
+up and (2) hold what the oracle returns now.
+
+  EXACT   every input is a pure function of seeds (`_random_case`): the key and the value are reproduced exactly.
+  DEVICE  the per-step permutations come from oracle/feistel_perm.py (integer-exact restatement of common.hpp perm_apply: the key
+          includes their bytes, so a hit also proves the restatement equals what the device exported when the entry was recorded),
+          the eps from oracle/device_draws.py (numpy Philox4x32-10 + Box-Muller).
+  FAST    the member schedule from oracle/device_draws.member_schedule (integer-exact; in the key likewise), the same eps.
+
+The memoised FAST / DEVICE values were computed from eps the DEVICE exported (hardware log / sqrt / sin / cos, ~1 ulp each); the
+numpy normals agree with those to ~1e-6 relative, so the recomputed returns agree to ~1e-6 x H, not bit for bit: the bound below
+is the tests' own T2 (|err| <= 1e-4 max(1, |v|)).  Workloads whose reward / termination is a threshold function of the state
+(cartpole: 0 / 1 per step) can flip one row's step on such an eps difference -- a return then moves by 1 / P; at most 0.5 % of a
+population's candidates may exceed T2 there, and never by more than 2 / P per step flipped (asserted).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_cache as oc
+from oracle import device_draws, feistel_perm
+from oracle import pets_oracle as po
+from test_gpu_rollout import DEVICE_SIZES, FAST_SIZES, SIZES, _random_case
+
+_IDS = lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}"  # noqa: E731
+
+
+def _group():
+    g = oc._groups.get("rollout_sizes") or oc._Group("rollout_sizes")
+    assert g.data, "tests/golden/oracle_cache/rollout_sizes.npz is missing or empty"
+    return g
+
+
+def _close(fresh, cached, om, P):
+    fresh, cached = fresh.double(), torch.from_numpy(cached).double()
+    err = (fresh - cached).abs()
+    tol = 1e-4 * torch.clamp(cached.abs(), min=1.0)
+    bad = err > tol
+    if om.reward in ("cartpole", "inverted_pendulum") or om.termination not in (None, "none"):
+        # threshold functions: an eps difference of 1e-7 may flip a row's step (see the module docstring)
+        assert bad.double().mean() <= 0.005, f"{int(bad.sum())} of {bad.numel()} candidates beyond T2"
+        return
+    assert not bad.any(), f"max |cached - fresh| {err.max():.3e} (T2 bound {tol[err.argmax()]:.3e})"
+
+
+@pytest.mark.parametrize("case", SIZES, ids=_IDS)
+def test_exact_entries_are_what_the_oracle_returns_now(case):
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, perms, eps = _random_case(obs, act, pop, P, H, **mkw)
+    key = oc._digest(["exact", *oc.model_parts(om), actions, s0, P, perms, eps])
+    g = _group()
+    assert key in g.data, "no memo entry under the key test_exact_mode_matches_oracle looks up"
+    fresh = po.rollout(om, actions, s0, P, perms=perms, eps=eps)
+    cached = torch.from_numpy(g.data[key])
+    # same inputs, same oracle, same torch build: equal up to the host's BLAS summation order
+    assert (fresh - cached).abs().max() <= 1e-4 * max(1.0, float(cached.abs().max())) * 0.5
+    assert torch.allclose(fresh, cached, rtol=2e-5, atol=2e-5)
+
+
+def _cpu_eps(om, H, B, seed, sid):
+    return None if om.deterministic else torch.from_numpy(device_draws.fast_normals(H, B, om.out_size, seed, sid))
+
+
+@pytest.mark.parametrize("case", DEVICE_SIZES, ids=_IDS)
+def test_device_entries_replayed_with_cpu_restatements_of_the_draws(case):
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    seed, sid = 4321, 5  # test_gpu_device_mode.py::test_device_mode_replayed_through_oracle
+    B = pop * P
+    perms = None
+    if om.propagation == "fixed_model":
+        perms = torch.from_numpy(feistel_perm.permutation(B, seed, sid, 0xFFFFFFFF))
+    elif om.propagation != "expectation":
+        perms = torch.from_numpy(np.stack([feistel_perm.permutation(B, seed, sid, t) for t in range(H)]))
+    key = oc._digest(["device", *oc.model_parts(om), actions, s0, P, perms, ("philox", seed, sid)])
+    g = _group()
+    assert key in g.data, "no memo entry under this key: the device's exported permutations differ from oracle/feistel_perm.py, or the entry was never recorded"
+    fresh = po.rollout(om, actions, s0, P, perms=perms, eps=_cpu_eps(om, H, B, seed, sid))
+    _close(fresh, g.data[key], om, P)
+
+
+@pytest.mark.parametrize("case", FAST_SIZES, ids=_IDS)
+def test_fast_entries_replayed_with_cpu_restatements_of_the_draws(case):
+    obs, act, pop, P, H, mkw = case
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
+    seed, sid = 1234, 77  # test_gpu_rollout.py::test_fast_mode_replayed_through_oracle
+    B, M = pop * P, len(om.active_members)
+    fixed = om.propagation == "fixed_model"
+    g = _group()
+    rows = torch.arange(B)
+    hit = None
+    for r in (1, 2, 3, 4):  # the row-tile count is the engine's choice (hipets_fast_geometry): the recorded entry names it through its key
+        nwg = ((pop + 16 * r - 1) // (16 * r)) * P
+        sched = torch.from_numpy(device_draws.member_schedule(1 if fixed else H, nwg, M, seed, sid, fixed=fixed, iid=om.ensemble_kind == "basic_ensemble"))
+        wg = ((rows // P) // (16 * r)) * P + rows % P
+        members = torch.stack([sched[0 if fixed else t][wg].long() for t in range(H)])
+        key = oc._digest(["fast", *oc.model_parts(om), actions, s0, P, members, ("philox", seed, sid)])
+        if key in g.data:
+            hit = (key, members)
+            break
+    assert hit, "no memo entry for any row-tile count: the device's exported schedule differs from oracle/device_draws.py, or the entry was never recorded"
+    key, members = hit
+    fresh = po.rollout(om, actions, s0, P, members=members, eps=_cpu_eps(om, H, B, seed, sid))
+    _close(fresh, g.data[key], om, P)
