@@ -305,15 +305,55 @@ __device__ __forceinline__ TailStages<P, F, G> make_tail(P p, F f, G g) { return
 #ifndef HIPETS_INTERLEAVE
 #define HIPETS_INTERLEAVE 1  // the next chunk's fragment loads inside the MFMAs' shadows (compute_il in wave_gemm)
 #endif
-template <int R, int CT, int EX, int ACT, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1>
+// x * rcp(1 + exp2(-x log2 e)) on the 4 accumulator values of a lane: the two multiplies and the add as packed 2 x f32 ops
+__device__ __forceinline__ f32x4 silu4(const f32x4 a) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
+    const f32x2 lo = {a[0], a[1]}, hi = {a[2], a[3]};
+    f32x2 tl = lo * k, th = hi * k;
+    tl[0] = __builtin_amdgcn_exp2f(tl[0]); tl[1] = __builtin_amdgcn_exp2f(tl[1]);
+    th[0] = __builtin_amdgcn_exp2f(th[0]); th[1] = __builtin_amdgcn_exp2f(th[1]);
+    tl = tl + one; th = th + one;
+    tl[0] = __builtin_amdgcn_rcpf(tl[0]); tl[1] = __builtin_amdgcn_rcpf(tl[1]);
+    th[0] = __builtin_amdgcn_rcpf(th[0]); th[1] = __builtin_amdgcn_rcpf(th[1]);
+    const f32x2 yl = lo * tl, yh = hi * th;
+    return f32x4{yl[0], yl[1], yh[0], yh[1]};
+}
+
+// K-SPLIT of the leftover column tile (one-tile workgroups, round 5; KSpec::KSPLIT).  A hidden layer of 13 column tiles deals 4-3-3-3
+// tiles to the four waves: the wave with four sets the pace of every layer (200 of its 4 x 50 MFMA k-steps against 150 of the
+// others), and at R = 1 nothing else runs on the CU.  Instead the 13th tile's K RANGE is dealt to the waves -- wave w takes the k
+// chunks [w KC / 4, (w + 1) KC / 4) of it, at most kKsSlots -- so every wave issues 3 x 50 + 16 k-steps, and the four partial sums
+// meet LAZILY: a wave leaves its partial (pre-activation; wave 0's starts at the bias) in LDS as the f32x4 its lanes hold -- which,
+// formed transposed, is exactly the B-operand fragment layout of the NEXT op's last k chunk (`lds_col`) -- and after the layer's
+// ordinary barrier every wave of the next op reads the four partials of its lane, adds them in one fixed order ((P0 + P1) + (P2 + P3))
+// and applies the activation: that IS its fragment of the last chunk.  No extra barrier, no extra pass; 4 ds_read_b128 + ~20 VALU
+// instructions per wave and layer against 34 k-steps (~1.1 k cycles) fewer on the critical wave.  The hidden columns 192..207 are
+// summed in another order than in the other instances: KSPLIT instances agree with them to rounding (tests: T2 against the oracle),
+// not bit for bit.  Two partial buffers alternate by layer parity (a fast wave may finish layer l + 1 while a slow one still reads
+// layer l's partials).
+constexpr int kKsSlots = 4;  // k chunks of the split tile per wave (KC <= 16: hidden widths up to 256, inputs up to 256 columns)
+struct KsArgs {
+    const float* part_in;  // KSI: [kWaves][64][4] the producer's partial sums of this op's LAST k chunk
+    float* part_out;       // KSO: [kWaves][64][4] this op's partial sums of its split column tile
+    int tile;              // KSO: the split column tile (the op's last)
+    int k0, n;             // KSO: this wave's chunks [k0, k0 + n) of it
+    int wave;
+};
+
+// KS bit 0 (KSI): the input image's last k chunk is NOT in LDS -- it is rebuilt from ks->part_in; bit 1 (KSO): see above
+template <int R, int CT, int EX, int ACT, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1, int KS = 0>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld_rt,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC_rt,
                                           const int tail_steps, const int c_first, const Extras ex,
                                           const bool apply_act, const int act, const float slope, const int lane,
                                           Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr,
-                                          const int ldi_rt = 0) {
+                                          const int ldi_rt = 0, const KsArgs* ks = nullptr) {
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
+    constexpr bool KSI = (KS & 1) != 0, KSO = (KS & 2) != 0;
+    static_assert(!KS || (R == 1 && LD > 0 && KCS <= 0 && !PRE && HIPETS_BUFFER_LOADS), "k-split: one-tile shape-specialised instances, rolled k loop");
+    static_assert(!KSO || (std::is_same<TL, NoTail>::value && EX == 0 && !SPL), "k-split producer: a hidden op");
     f32x4 acc[CTn][R];
     f32x4 accx[EXn];
     const int ld = LD > 0 ? LD : ld_rt;
@@ -533,6 +573,23 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
 
     // sched_barrier(0) pins "issue the next chunk's loads, THEN this chunk's MFMAs": without it the machine
     // scheduler sinks each load group down to its first use and the pipeline degenerates to load->wait->compute.
+    // k-split: the partials of the input's last chunk (KSI) and this wave's share of the split tile (KSO: its weight and activation
+    // fragments, ALL requested up front -- unused slots read chunk 0 and are zeroed below: straight-line code, no branch around an MFMA)
+    f32x4 ks_p[kWaves], ks_b[kKsSlots], ks_a[kKsSlots], ks_bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KSI) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) ks_p[w] = *reinterpret_cast<const f32x4*>(ks->part_in + (w * 64 + lane) * 4);
+    }
+    if constexpr (KSO) {
+        const unsigned xoff = (unsigned)((ks->tile * KC * 64 + lane) * 16);
+        ks_bias = *reinterpret_cast<const f32x4*>(bias + ks->tile * 16 + 4 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < kKsSlots; ++j) {
+            const int c = j < ks->n ? ks->k0 + j : 0;
+            ks_b[j] = wload(xoff, c);
+            ks_a[j] = *reinterpret_cast<const f32x4*>(ap + c * 16);
+        }
+    }
     GemmFrags<R, CT, EX> f0, f1;
     if constexpr (PRE) {  // chunk 0: weights are in registers already, only the activation fragments come from LDS
 #pragma unroll
@@ -575,6 +632,40 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     }
     if constexpr (kSplit) pin(acc_odd);
     prof.mark(14);
+    f32x4 a_last = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KSI) {  // this lane's fragment of the input's last chunk: the activation of the four partial sums, in ONE fixed order
+        static_assert(ACT == HIPETS_ACT_SILU, "k-split instances are SiLU instances");
+        a_last = silu4((ks_p[0] + ks_p[1]) + (ks_p[2] + ks_p[3]));
+    }
+    f32x4 ks_e = f32x4{0.f, 0.f, 0.f, 0.f}, ks_o = f32x4{0.f, 0.f, 0.f, 0.f};  // even / odd k-steps of the split tile (hazard (2) above)
+    if constexpr (KSO) {
+        // Wave-uniform choices as ARITHMETIC (a multiply by 1.0f or 0.0f from an SGPR: exact on finite values), never as control flow:
+        // written as `if`s the compiler built a web of ~40 scalar branches around these 20 register writes
+        ks_e = ks_bias * (ks->wave == 0 ? 1.0f : 0.0f);  // the sum of the four partials carries the bias once
+#pragma unroll
+        for (int j = 0; j < kKsSlots; ++j) ks_b[j] = ks_b[j] * (j < ks->n ? 1.0f : 0.0f);  // unused slot: 0 x (a valid activation of chunk 0)
+        if constexpr (KSI) {
+            // the input's last chunk lives in registers (a_last), not in LDS.  In an op fed by a hidden layer it is the LAST slot of the
+            // LAST wave (KC = 13 .. 16: wave 3 holds chunks [3 KC / 4, KC), four of them); on the other waves that slot is unused (zero
+            // weights), so it may hold the same finite values there: no selection at all
+            HIPETS_BOUND(KC >= 13 && KC <= 16);
+            ks_a[kKsSlots - 1] = a_last;
+        }
+        pin(ks_e);
+        pin(ks_o);
+#pragma unroll
+        for (int j = 0; j < kKsSlots; ++j) {
+            pin(ks_b[j]);
+            pin(ks_a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kKsSlots; ++j)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                asm volatile("s_nop 1");
+                mfma16x16x4(ks_b[j][s_], ks_a[j][s_], (s_ & 1) ? ks_o : ks_e);
+            }
+    }
     if constexpr (KCS > 0) {
         constexpr int kEnd = KCS >= 2 ? ((KCS - 1) / 2) * 2 : 0;  // the loop below leaves kk at the smallest even number >= KCS - 2
 #pragma unroll
@@ -623,7 +714,20 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (kk > 0) drain_all();
+        // (k-split instances drain unconditionally: their register allocation copies the accumulators where the tail's arms begin, and
+        // the build's ISA scan cannot know that the path "loop left with results in flight AND kk == 0" does not exist)
+        if (KS != 0 || kk > 0) drain_all();
+        // KSI: the last chunk's activation fragment is a_last (what the loads above fetched from that LDS position is unwritten space)
+        auto last_frag = [&](GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {
+            if constexpr (KSI) {
+                if constexpr (CT > 0) f.a[0] = a_last;
+#pragma unroll
+                for (int e = 0; e < EX; ++e) f.ax[e] = a_last;
+                if constexpr (CT > 0) pin(f.a[0]);
+#pragma unroll
+                for (int e = 0; e < EX; ++e) pin(f.ax[e]);
+            }
+        };
         if (kk + 1 < KC) {  // two chunks left: kk (full) and kk+1 (tail)
             if constexpr (kIL) {
                 compute_il(f0, f1, kk + 1);
@@ -633,8 +737,11 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                 compute(f0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (KS != 0) drain_all();  // (the allocator copies the accumulators where the tail's arms begin: see above)
+            last_frag(f1);
             compute_tail(f1);
         } else {  // one chunk left
+            last_frag(f0);
             compute_tail(f0);
         }
     }
@@ -692,6 +799,14 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         return;
     }
 
+    if constexpr (KSO) {
+        // this wave's partial sum of the split tile -> LDS, as the f32x4 the lane holds (= the next op's fragment layout).  The two
+        // accumulators are re-defined behind the drain above: to the compiler an asm MFMA's result is ready at once, and it would
+        // otherwise be free to form this sum right behind the mini-loop, while the matrix pipe still writes the registers
+        asm volatile("" : "+v"(ks_e));
+        asm volatile("" : "+v"(ks_o));
+        *reinterpret_cast<f32x4*>(ks->part_out + (ks->wave * 64 + lane) * 4) = ks_e + ks_o;
+    }
     // epilogue: D[row = 4*(lane>>4)+i][col = lane&15] -> bias, activation, next layer's A image.
     // The activation switch is hoisted OUT of the element loops: one compact straight-line body per
     // activation (a per-element switch made the hot path stream ~12 KB of mostly-skipped code per layer
@@ -726,21 +841,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
         store([](const f32x4 a) { return a; });
     } else {
         switch (ACT >= 0 ? ACT : act) {
-            case HIPETS_ACT_SILU:  // x * rcp(1 + exp2(-x log2 e)): the two multiplies and the add as packed 2 x f32 ops
-                store([](const f32x4 a) {
-                    using f32x2 = __attribute__((ext_vector_type(2))) float;
-                    const f32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
-                    const f32x2 lo = {a[0], a[1]}, hi = {a[2], a[3]};
-                    f32x2 tl = lo * k, th = hi * k;
-                    tl[0] = __builtin_amdgcn_exp2f(tl[0]); tl[1] = __builtin_amdgcn_exp2f(tl[1]);
-                    th[0] = __builtin_amdgcn_exp2f(th[0]); th[1] = __builtin_amdgcn_exp2f(th[1]);
-                    tl = tl + one; th = th + one;
-                    tl[0] = __builtin_amdgcn_rcpf(tl[0]); tl[1] = __builtin_amdgcn_rcpf(tl[1]);
-                    th[0] = __builtin_amdgcn_rcpf(th[0]); th[1] = __builtin_amdgcn_rcpf(th[1]);
-                    const f32x2 yl = lo * tl, yh = hi * th;
-                    return f32x4{yl[0], yl[1], yh[0], yh[1]};
-                });
-                break;
+            case HIPETS_ACT_SILU: store([](const f32x4 a) { return silu4(a); }); break;
             case HIPETS_ACT_RELU: store(each([](float x) { return x < 0.0f ? 0.0f : x; })); break;  // NOT fmaxf: v_max_f32 returns 0 for a NaN input, torch.relu returns NaN
             case HIPETS_ACT_LEAKY_RELU: store(each([slope](float x) { return x > 0.0f ? x : slope * x; })); break;
             case HIPETS_ACT_TANH: store(each([](float x) { return tanhf(x); })); break;
@@ -776,13 +877,29 @@ __device__ __forceinline__ void wave_gemm_ex(int nex, const float* in, float* ou
 // CS >= 0: the number of column tiles is a compile-time fact (shape-specialised kernels): every wave's (CT, EX) follows
 // from it and the wave index through ONE branch, and only the two wave_gemm instances the shape needs are compiled;
 // CS < 0: it is read from the layer table and dispatched through the (full, nex) switches.
-template <int R, int ACT = -1, int CS = -1, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1>
+// KS (shape-specialised ops of one-tile workgroups): wave_gemm's k-split bits; part_in / part_out: the partial-sum buffers (KsArgs)
+template <int R, int ACT = -1, int CS = -1, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1, int KS = 0>
 __device__ __forceinline__ void linear_op(const float* W, const float* bias, const LayerMeta lm, const int ld, const bool apply_act,
                                           const int activation, const float slope, const float* in, float* out, const int wave,
                                           const int lane, Prof& prof, Pre* pre = nullptr, const NextOp* nxt = nullptr, const TL* tl = nullptr,
-                                          const int ldi = 0) {
+                                          const int ldi = 0, const float* part_in = nullptr, float* part_out = nullptr) {
     static_assert(std::is_same<TL, NoTail>::value || CS >= 0, "a fused tail needs a shape-specialised op");
+    static_assert(!KS || CS >= 0, "k-split needs a shape-specialised op");
     const int KC = lm.Kp / kKChunk;
+    if constexpr ((KS & 2) != 0) {
+        // k-split producer: the CS - 1 strided tiles as usual (CS / 4 per wave, no leftover units), the last tile's k range dealt to the waves
+        static_assert(CS % kWaves == 1 && CS / kWaves >= 1 && CS / kWaves <= 3, "k-split: one leftover column tile");
+        KsArgs ks;
+        ks.part_in = part_in; ks.part_out = part_out; ks.tile = CS - 1; ks.wave = wave;
+        ks.k0 = (wave * KC) / kWaves;
+        ks.n = ((wave + 1) * KC) / kWaves - ks.k0;
+        Extras ex0;
+        ex0.c0 = ex0.c1 = ex0.c2 = ex0.c3 = 0; ex0.r0 = ex0.r1 = ex0.r2 = ex0.r3 = 0;
+        wave_gemm<R, CS / kWaves, 0, ACT, false, NoTail, LD, false, -1, KS>(in, out, ld, W, bias, KC, lm.tail_steps, wave, ex0, apply_act, activation, slope, lane, prof,
+                                                                            nullptr, nullptr, nullptr, ldi, &ks);
+    } else {
+    KsArgs ks;  // (KS == 1: a consumer only -- the output layer)
+    ks.part_in = part_in; ks.part_out = nullptr; ks.tile = 0; ks.k0 = 0; ks.n = 0; ks.wave = wave;
     // a wave's strided column tiles go through in passes of at most kMaxCT tiles (accumulator + double-buffered
     // fragment registers must fit the 256 VGPRs two waves per SIMD leave each wave)
     constexpr int kMaxCT = kWaves >= 8 ? 2 : 3;
@@ -810,14 +927,14 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         static_assert(!PRE || passes == 0, "cross-layer prefetch needs the op to fit one wave_gemm per wave");
         if constexpr (lo == hi) {
             if constexpr (last > 0 || lo > 0)
-                wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
+                wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS, KS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi, &ks);
             else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);  // nothing to compute here: still fetch for the next op
         } else {
             if (wave < nu % kWaves) {
-                wave_gemm<R, last, hi, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
+                wave_gemm<R, last, hi, ACT, PRE, TL, LD, SPL, KCS, KS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi, &ks);
             } else {
                 if constexpr (last > 0 || lo > 0)
-                    wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi);
+                    wave_gemm<R, last, lo, ACT, PRE, TL, LD, SPL, KCS, KS>(in, out, ld, W, bias, KC, lm.tail_steps, c_first, ex, apply_act, activation, slope, lane, prof, pre, nxt, tl, ldi, &ks);
                 else if constexpr (PRE) prefetch_issue(*nxt, lane, *pre);
             }
         }
@@ -849,6 +966,7 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
                 break;
         }
     }
+    }  // (not a k-split producer)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1120,6 +1238,12 @@ struct KSpec {
     // (output layers of up to 8 column tiles: beyond that -- cfg4' has 47 -- a wave's tail covers a dozen units and the instance spills)
     static constexpr bool FUSE = FUSE_ != 0 && LEAN && PREC_ == HIPETS_PREC_F32 && (OUTC_ <= kSplMaxTiles || WIDE);
     static constexpr bool SPL_OUT = OUTC_ >= 0 && OUTC_ <= kSplMaxTiles;  // the output layer sums even / odd k-steps separately (wave_gemm SPL)
+    // K-split of the leftover hidden column tile (KsArgs above): the fused fp32 instances whose hidden layers leave ONE column tile over
+    // (13 = 3 x 4 + 1), used by the kernel for ONE-TILE workgroups only (R = 1: rollout_kernel's kKS)
+#ifndef HIPETS_KSPLIT
+#define HIPETS_KSPLIT 1
+#endif
+    static constexpr bool KSPLIT = HIPETS_KSPLIT && FUSE && !WIDE && HIDC_ % kWaves == 1 && HIDC_ / kWaves >= 1 && HIDC_ / kWaves <= 3 && HIDC_ <= 16;
     // termination functions that test EVERY state dim (inverted_pendulum: isfinite(next_obs).all(), termination_fns.py:47-55) are fused for
     // models with obs_dim <= 4 only -- then dims 0..3 ARE every dim (launch.hpp fused_term_ok checks the model)
     static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS || REW_ == HIPETS_REW_LEARNED) &&
@@ -1198,13 +1322,21 @@ __device__ __forceinline__ void mlp_layer_b3(const ModelDev& md, const LayerMeta
 }
 
 // Layer l of the ensemble MLP with member `member`'s weights.
+// part: the two k-split partial-sum buffers of a KSpec::KSPLIT one-tile workgroup ([2][kWaves][64][4] floats, alternating by layer)
 template <int R, class S>
 __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* lmeta, const int l, const int member,
-                                          const float* in, float* out, const int wave, const int lane, Prof& prof) {
+                                          const float* in, float* out, const int wave, const int lane, Prof& prof, float* part = nullptr) {
     const LayerMeta lm = lmeta[l];  // staged in LDS once per launch (a global scalar load here cost ~400 cycles per layer)
     const float* W = md.w + (size_t)member * md.wmember + lm.woff;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff;
-    if constexpr (S::LEAN) {
+    if constexpr (S::KSPLIT && R == 1) {
+        // hidden ops of a one-tile workgroup: every wave 3 column tiles + its quarter of the 13th tile's k range (wave_gemm KSO); ops fed
+        // by a hidden layer rebuild their last k chunk from the previous op's partial sums (KSI)
+        float* const po = part + (l & 1) * (kWaves * 64 * 4);
+        const float* const pi = part + ((l & 1) ^ 1) * (kWaves * 64 * 4);
+        if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, -1, 2>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, 0, nullptr, po);
+        else linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, -1, 3>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, 0, pi, po);
+    } else if constexpr (S::LEAN) {
         // ops fed by a hidden layer have K = hid: HIDC chunks, a compile-time count (the input layer's K is the model's input width)
         // Unrolled only where the register file is not the constraint (R >= 3: one workgroup per CU, 512 registers per lane).  At R = 2
         // (two workgroups per CU, 256-register cap) the allocator splits accumulator live ranges inside the unrolled stream and
@@ -1235,11 +1367,16 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
 // The OUTPUT layer of a KSpec::FUSE instance: the "head pair" pack, accumulators handed to `tl` (no LDS image of the outputs)
 template <int R, class S, class TL>
 __device__ __forceinline__ void mlp_output_layer_fused(const ModelDev& md, const LayerMeta* lmeta, const int member, const float* in,
-                                                       const int wave, const int lane, Prof& prof, const TL& tl) {
+                                                       const int wave, const int lane, Prof& prof, const TL& tl, const float* part = nullptr) {
     const LayerMeta lm = lmeta[md.n_layers - 1];
     const float* W = md.w + (size_t)member * md.wmember + lm.woff_pairs;
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff_pairs;
-    linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
+    if constexpr (S::KSPLIT && R == 1) {  // the last hidden layer (index n_layers - 2) left its 13th tile as partial sums
+        const float* const pi = part + ((md.n_layers - 2) & 1) * (kWaves * 64 * 4);
+        linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, -1, 1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl, 0, pi);
+    } else {
+        linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
+    }
 }
 
 // obs_process_fn seen from the PRODUCER of an observation dim (the fused tail, the straight form's collect phase: both hold a pair
@@ -1366,6 +1503,7 @@ struct RolloutSmem {
     LayerMeta* lmeta;  // [HIPETS_MAX_LAYERS]
     long long* prof;   // [kWaves][16] phase-cycle accumulators (profiling aid)
     float* dump;     // [4] sink of the fused tail's masked-off LDS stores (branch-free: an inactive lane stores here)
+    float* part;     // one-tile workgroups: [2][kWaves][64][4] k-split partial sums (KsArgs)
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
 };
 
@@ -1386,6 +1524,7 @@ __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_d
     n += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
     n += align16((size_t)kWaves * 16 * 8);
     n += 16;  // dump slot
+    if (rows == kTile) n += (size_t)2 * kWaves * 64 * 16;  // one-tile workgroups: the k-split partial sums (RolloutSmem::part)
     if (expectation) n += align16((size_t)rows * out_total * 4);
     return n;
 }
@@ -1458,6 +1597,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         sm.lmeta = reinterpret_cast<LayerMeta*>(p); p += align16(sizeof(LayerMeta) * HIPETS_MAX_LAYERS);
         sm.prof = reinterpret_cast<long long*>(p); p += align16((size_t)kWaves * 16 * 8);
         sm.dump = reinterpret_cast<float*>(p); p += 16;
+        sm.part = reinterpret_cast<float*>(p); p += (ROWS == kTile) ? (size_t)2 * kWaves * 64 * 16 : 0;
         sm.state = reinterpret_cast<float*>(p); p += align16((size_t)ROWS * md.obs_dim * 4);
         sm.actn = reinterpret_cast<float*>(p); p += align16((size_t)2 * ROWS * md.act_dim * 4);
         sm.nmean = reinterpret_cast<double*>(p); p += align16((size_t)md.in_dim * 8);
@@ -1470,7 +1610,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #if HIPETS_DEBUG_BOUNDS
         {   // every section starts inside the launch's dynamic LDS, 16-byte aligned, in layout order; the last one ends inside it
             const char* const secs[] = {(char*)sm.buf0, (char*)sm.buf1, (char*)sm.tot, (char*)sm.lrew, (char*)sm.term, (char*)sm.rowid, (char*)sm.pend,
-                                        (char*)sm.lmeta, (char*)sm.prof, (char*)sm.dump, (char*)sm.state, (char*)sm.actn, (char*)sm.nmean, (char*)sm.nstd,
+                                        (char*)sm.lmeta, (char*)sm.prof, (char*)sm.dump, (char*)sm.part, (char*)sm.state, (char*)sm.actn, (char*)sm.nmean, (char*)sm.nstd,
                                         (char*)sm.minlv, (char*)sm.maxlv, (char*)sm.nodelta, (char*)sm.sched, (char*)sm.expacc};
             constexpr int kSecs = (int)(sizeof(secs) / sizeof(secs[0]));
             for (int i = 0; i < kSecs; ++i) {
@@ -2037,7 +2177,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     fetch_actions_issue(t + 1, av);
                 }
                 if (l == L - 2 && (write_input || prep_next || wide_fast_next)) fetch_actions_commit(t + 1, av);
-                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof);
+                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof, sm.part);
                 __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
@@ -2191,7 +2331,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             auto tail_finish = [&]() __attribute__((always_inline)) {};
             const auto tail = make_tail(tail_prep, tail_unit, tail_finish);
             prof.mark(12);
-            mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail);
+            mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
             // straight persistent form: what the two sides of this barrier exchange goes through LDS; the tail's write-through
             // hand-over stores need not have been acknowledged (__syncthreads() would wait for that -- about a microsecond --
             // before the first poll for the incoming rows is even issued; this way the two round trips overlap)

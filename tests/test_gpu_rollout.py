@@ -410,6 +410,20 @@ def test_gaussian_mlp_with_explicit_member_maps(engine, prop):
     assert torch.allclose(nobs.cpu(), r_nobs, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), r_rew, rtol=1e-5, atol=2e-6)
 
 
+def assert_same_arithmetic(a, b, row_tiles):
+    """Two instances of the rollout kernel on the same call.  Bit for bit -- except where one of them is a FUSED instance with ONE row
+    tile per workgroup: those deal the k range of the 13th hidden column tile to the four waves (rollout.hpp KsArgs, round 5), i.e.
+    sum hidden columns 192..207 in another order; they agree with every other instance to rounding, which is held to a tenth of the
+    tolerance the same returns get against the oracle (T2)."""
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    if row_tiles != 1:
+        assert torch.equal(a, b)
+        return
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    bad = (a - b).abs() > 1e-5 * torch.clamp(b.abs(), min=1.0)
+    assert not bad.any(), f"max |a - b| {(a - b).abs().max():.3e} at candidate {int(bad.nonzero()[0])}"
+
+
 @pytest.mark.parametrize("mode", ["fast", "device"])
 @pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[3], SIZES[4]], ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}")
 def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case, mode):
@@ -422,8 +436,8 @@ def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case
     a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3)
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=True)
     c = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=2)  # the hidden-static instance
-    assert torch.equal(a, b) and torch.equal(a, c)
-    assert torch.isfinite(a).all()
+    assert torch.equal(b, c)
+    assert_same_arithmetic(a, b, engine.kernel_class(pop, P, H, mode)[1])
 
 
 # every model of the reference's default hidden width (200) that has no shape-specialised instance: the workloads the reference
@@ -468,7 +482,9 @@ def test_hidden_static_instances_equal_the_generic_kernel_bitwise(engine, case, 
     engine.set_model(to_spec(om, obs, act))
     a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
-    assert torch.equal(a, b) and torch.isfinite(a).all()
+    c = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=2)
+    assert torch.equal(b, c)  # hidden-static == generic, for every row-tile count
+    assert_same_arithmetic(a, b, rows_per_group or engine.kernel_class(pop, P, H, mode)[1])  # ... and the call's own (maybe fused) instance
 
 
 # the other hidden widths with hidden-static instances: 8 and 16 column tiles (hid 113..128, 241..256)
@@ -534,7 +550,7 @@ def test_shipped_workloads_run_the_instance_class_the_docs_say(engine, wl, mode)
     assert cls == (want[mode] if isinstance(want, dict) else want) and 1 <= r <= 4
     a = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r)
     b = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r, generic_kernel=True)
-    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert_same_arithmetic(a, b, r)
 
 
 def test_kernel_class_of_other_models(engine):
