@@ -191,6 +191,9 @@ size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
 // instead of 4 per row tile at hid 200).  Step-synchronous launches (DEVICE / EXACT: hand-over or one launch per step) pay the busiest one.
 // Calibrated on MI355X (profiles/r4_stock_workloads.json, r4_learned_reward_workloads.json, r4_device_r_sweep.json: every R forced, 12
 // workloads, both modes -- the rule picks the fastest R in 23 of the 24 cases and loses 0.3 % in the other).
+// member_schedule_kernel: blocks per (step, rollout) -- one per 256 workgroups whose slot they rank (rollout_helpers.hpp)
+inline unsigned schedule_slices(int nwg) { return (unsigned)std::max(1, std::min(64, (nwg + 255) / 256)); }
+
 int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (waves w and w + 4 share SIMD w % 4)
     const int full = C / kWaves, rem = C % kWaves, nu = rem * R;
     int simd[4] = {0, 0, 0, 0};
@@ -299,7 +302,7 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
     const int nwg = (int)((tiles + R - 1) / R) * P;
     if (nwg > 8000) return 0;  // the rollout reports the error
     if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
-    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, iters), dim3(256), (size_t)nwg * 8, st, e->plan_schedule.as<int>(), nwg, md.M,
+    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, iters, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->plan_schedule.as<int>(), nwg, md.M,
                        md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)seed,
                        (unsigned long long)first_stream);
     HCHECK(hipGetLastError());
@@ -925,7 +928,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
                 ra.schedule = presched;
             } else {
                 if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
-                hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
+                hipLaunchKernelGGL(member_schedule_kernel, dim3(H, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
                                    md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
                                    (unsigned long long)o->stream_id);
                 HCHECK(hipGetLastError());
@@ -1102,7 +1105,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
                 ra.schedule = o->member_schedule;
             } else {
                 if (e->schedule.ensure((size_t)nwg * 4)) return 1;
-                hipLaunchKernelGGL(member_schedule_kernel, dim3(1), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
+                hipLaunchKernelGGL(member_schedule_kernel, dim3(1, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
                                    md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
                                    (unsigned long long)o->stream_id);
                 HCHECK(hipGetLastError());
@@ -1121,7 +1124,7 @@ int hipets_fast_schedule(hipets_engine* e, int32_t H, int32_t nwg, uint64_t seed
     if (!e || !e->has_model) return fail("engine has no model");
     if (!schedule || H < 1 || nwg < 1) return fail("bad argument");
     HCHECK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(member_schedule_kernel, dim3(H), dim3(256), (size_t)nwg * 8, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
+    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
                        e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, e->md.iid_members, (unsigned long long)seed,
                        (unsigned long long)stream_id);
     HCHECK(hipGetLastError());

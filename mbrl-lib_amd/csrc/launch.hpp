@@ -44,22 +44,24 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
 #define HIPETS_LEAN_SHAPES_R1(X)                                                                                                               \
     X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
-    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
+    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
+    X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
 #define HIPETS_LEAN_SHAPES_R2(X)                                                                                                               \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 47, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
     X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
     X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE, HIPETS_OBS_NONE)                                                                        \
-    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH)
+    X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 3, HIPETS_REW_LEARNED, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) \
+    X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
 //   pets_inv_pendulum (learned reward + the inverted_pendulum termination function, obs 4 / act 1, pop 480 x 20): R = 3.
 #define HIPETS_LEAN_SHAPES_R3(X)                                                                                                               \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_NONE) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE) \
     X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE, HIPETS_OBS_HALFCHEETAH) X(13, 1, HIPETS_REW_CARTPOLE_PETS, HIPETS_TERM_NONE, HIPETS_OBS_CARTPOLE_PETS) \
     X(13, 1, HIPETS_REW_LEARNED, HIPETS_TERM_INVERTED_PENDULUM, HIPETS_OBS_NONE)
 #define HIPETS_LEAN_SHAPES_R4(X) X(13, 6, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_HUMANOID, HIPETS_OBS_NONE)
-// Shapes with FAST instances ONLY (KSpec: termination functions over every state dim of a model wider than one column tile --
-// pets_hopper: obs 11 / act 3, learned reward, pop 350 x 20 -> R = 1; DEVICE-mode calls of these models run the hidden-static instance)
-#define HIPETS_LEAN_FAST_SHAPES_R1(X) X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
-#define HIPETS_LEAN_FAST_SHAPES_R2(X) X(13, 2, HIPETS_REW_LEARNED, HIPETS_TERM_HOPPER, HIPETS_OBS_NONE)
+// Shapes with FAST instances ONLY: none since round 5 (pets_hopper -- a termination function over every state dim of a model wider
+// than one column tile: obs 11 / act 3, learned reward, pop 350 x 20 -- was one until its DEVICE-mode instances existed: the tables above)
+#define HIPETS_LEAN_FAST_SHAPES_R1(X)
+#define HIPETS_LEAN_FAST_SHAPES_R2(X)
 #define HIPETS_LEAN_FAST_SHAPES_R3(X)
 #define HIPETS_LEAN_FAST_SHAPES_R4(X)
 

@@ -305,6 +305,9 @@ __device__ __forceinline__ TailStages<P, F, G> make_tail(P p, F f, G g) { return
 #ifndef HIPETS_INTERLEAVE
 #define HIPETS_INTERLEAVE 1  // the next chunk's fragment loads inside the MFMAs' shadows (compute_il in wave_gemm)
 #endif
+#ifndef HIPETS_KS_TRIPLE
+#define HIPETS_KS_TRIPLE 1  // k-split (one-tile) instances: fragments fetched TWO chunks ahead (three register sets, wave_gemm kTriple)
+#endif
 // x * rcp(1 + exp2(-x log2 e)) on the 4 accumulator values of a lane: the two multiplies and the add as packed 2 x f32 ops
 __device__ __forceinline__ f32x4 silu4(const f32x4 a) {
     using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     constexpr int CTn = CT > 0 ? CT : 1;
     constexpr int EXn = EX > 0 ? EX : 1;
     constexpr bool KSI = (KS & 1) != 0, KSO = (KS & 2) != 0;
-    static_assert(!KS || (R == 1 && LD > 0 && KCS <= 0 && !PRE && HIPETS_BUFFER_LOADS), "k-split: one-tile shape-specialised instances, rolled k loop");
+    static_assert(!KS || (R == 1 && LD > 0 && !PRE && HIPETS_BUFFER_LOADS), "k-split: one-tile shape-specialised instances, rolled k loop");
     static_assert(!KSO || (std::is_same<TL, NoTail>::value && EX == 0 && !SPL), "k-split producer: a hidden op");
     f32x4 acc[CTn][R];
     f32x4 accx[EXn];
@@ -603,6 +606,13 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
     } else {
         load(f0, 0);
     }
+    // One-tile k-split instances fetch TWO chunks ahead (kTriple below): a wave's 12 MFMAs per chunk (384 cycles) are no cover for an
+    // L2 round trip issued somewhere inside the previous chunk
+    // (ops whose chunk count is a compile-time fact -- KCS: everything fed by a hidden layer -- so that the loop's remainder is no run-time
+    // branch: the allocator copies accumulators where such arms begin and sinks the copies to just in front of their first MFMA)
+    constexpr bool kTriple = HIPETS_KS_TRIPLE && KS != 0 && KCS > 0 && HIPETS_INTERLEAVE && LD > 0;
+    static_assert(!KS || KCS <= 0 || kTriple, "k-split ops with a static chunk count run the three-set loop");
+    if constexpr (kTriple) load(f1, KCS > 1 ? 1 : 0);
     // accumulators start at the bias (C input of the first MFMA) instead of zero: no add in the epilogue.  Initialised AFTER
     // chunk 0's fragment loads were issued: the bias loads are older, so waiting for them leaves the fragments in flight
     // (initialising first serialised two L2 round trips per layer: ~1.2k cycles of "set-up" per layer in the phase profile)
@@ -666,7 +676,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                 mfma16x16x4(ks_b[j][s_], ks_a[j][s_], (s_ & 1) ? ks_o : ks_e);
             }
     }
-    if constexpr (KCS > 0) {
+    if constexpr (KCS > 0 && !kTriple) {
         constexpr int kEnd = KCS >= 2 ? ((KCS - 1) / 2) * 2 : 0;  // the loop below leaves kk at the smallest even number >= KCS - 2
 #pragma unroll
         for (int kk = 0; kk + 2 < KCS; kk += 2) {
@@ -696,6 +706,45 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
             compute_tail(f1);
         } else {
             compute_tail(f0);
+        }
+    } else if constexpr (kTriple) {
+        // three fragment sets in rotation: chunk kk is computed from one while chunk kk + 2 is being fetched into another (measured
+        // on MI355X, one-tile workgroups, round 5: with one chunk of lead the k loop of a wave with 3 column tiles ran at the pace of
+        // the L2 round trips, not of its MFMAs -- profiles/r5_small_batches.json)
+        GemmFrags<R, CT, EX> f2;
+        auto last_frag = [&](GemmFrags<R, CT, EX>& f) __attribute__((always_inline)) {  // KSI: see the two-set loop below
+            if constexpr (KSI) {
+                if constexpr (CT > 0) f.a[0] = a_last;
+#pragma unroll
+                for (int e = 0; e < EX; ++e) f.ax[e] = a_last;
+                if constexpr (CT > 0) pin(f.a[0]);
+#pragma unroll
+                for (int e = 0; e < EX; ++e) pin(f.ax[e]);
+            }
+        };
+        constexpr int kEnd3 = KCS >= 3 ? ((KCS - 1) / 3) * 3 : 0;  // where the loop below leaves kk
+        constexpr int kRem = KCS - kEnd3;                          // 1 .. 3 chunks left then, the last of them the tail chunk
+#pragma nounroll
+        for (int kk = 0; kk + 3 < KCS; kk += 3) {  // chunks kk .. kk + 2 are full ones; f0 = chunk kk, f1 = chunk kk + 1 on entry
+            compute_il(f0, f2, kk + 2);
+            compute_il(f1, f0, kk + 3);
+            compute_il(f2, f1, min(kk + 4, KCS - 1));  // (past the end: the last chunk once more, never used)
+        }
+        drain_all();
+        if constexpr (kRem == 1) {
+            last_frag(f0);
+            compute_tail(f0);
+        } else if constexpr (kRem == 2) {
+            compute(f0);
+            drain_all();
+            last_frag(f1);
+            compute_tail(f1);
+        } else {
+            compute_il(f0, f2, kEnd3 + 2);
+            compute(f1);
+            drain_all();
+            last_frag(f2);
+            compute_tail(f2);
         }
     } else {
         int kk = 0;
@@ -895,7 +944,7 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         ks.n = ((wave + 1) * KC) / kWaves - ks.k0;
         Extras ex0;
         ex0.c0 = ex0.c1 = ex0.c2 = ex0.c3 = 0; ex0.r0 = ex0.r1 = ex0.r2 = ex0.r3 = 0;
-        wave_gemm<R, CS / kWaves, 0, ACT, false, NoTail, LD, false, -1, KS>(in, out, ld, W, bias, KC, lm.tail_steps, wave, ex0, apply_act, activation, slope, lane, prof,
+        wave_gemm<R, CS / kWaves, 0, ACT, false, NoTail, LD, false, KCS, KS>(in, out, ld, W, bias, KC, lm.tail_steps, wave, ex0, apply_act, activation, slope, lane, prof,
                                                                             nullptr, nullptr, nullptr, ldi, &ks);
     } else {
     KsArgs ks;  // (KS == 1: a consumer only -- the output layer)
@@ -1255,8 +1304,12 @@ struct KSpec {
     // step and is folded into the row's `terminated` by the tail of step t + 1 -- which is when it first matters (model_env.py:186-188:
     // the reward of the terminating step itself still counts).  The row must still be HERE then: FAST instances only (in the persistent
     // DEVICE form it has moved to another workgroup, which would need the flag through the hand-over table); learned rewards only.
-    static_assert(!FUSE || TERM_ != HIPETS_TERM_HOPPER || (REW_ == HIPETS_REW_LEARNED && KMODE_ == HIPETS_MODE_FAST && !WIDE),
-                  "fused tail with an all-dims termination function: FAST instances with a learned reward");
+    // Round 5: DEVICE-mode instances too.  One launch per step: the flag of the launch's step is folded into `terminated` behind the
+    // step loop, before the write-back.  Persistent form: the row has moved on -- and its NEXT owner holds every dim of the state it
+    // receives: the threads that collect a pair of dims judge them exactly like the tail lanes would have and raise the flag in the
+    // new owner's LDS (hop_flags below); nothing more travels through the hand-over table.
+    static_assert(!FUSE || TERM_ != HIPETS_TERM_HOPPER || (REW_ == HIPETS_REW_LEARNED && !WIDE),
+                  "fused tail with an all-dims termination function: instances with a learned reward");
     // learned rewards (round 4): the reward is the sampled LAST output column.  Without a termination function (pets_pusher / pets_reacher /
     // pets_mppi_halfcheetah) the lane that holds that column keeps the row's running total and needs no state dim at all; with one
     // (pets_inv_pendulum) the lane with dims 0, 1 keeps it and fetches the reward from the column's lane of the SAME accumulator, i.e. the
@@ -1335,7 +1388,7 @@ __device__ __forceinline__ void mlp_layer(const ModelDev& md, const LayerMeta* l
         float* const po = part + (l & 1) * (kWaves * 64 * 4);
         const float* const pi = part + ((l & 1) ^ 1) * (kWaves * 64 * 4);
         if (l == 0) linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, -1, 2>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, 0, nullptr, po);
-        else linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, -1, 3>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, 0, pi, po);
+        else linear_op<R, S::ACT, S::HIDC, false, NoTail, S::LD, false, HIPETS_KS_TRIPLE ? S::HIDC : -1, 3>(W, bias, lm, md.ld, true, md.activation, md.slope, in, out, wave, lane, prof, nullptr, nullptr, nullptr, 0, pi, po);
     } else if constexpr (S::LEAN) {
         // ops fed by a hidden layer have K = hid: HIDC chunks, a compile-time count (the input layer's K is the model's input width)
         // Unrolled only where the register file is not the constraint (R >= 3: one workgroup per CU, 512 registers per lane).  At R = 2
@@ -1373,7 +1426,7 @@ __device__ __forceinline__ void mlp_output_layer_fused(const ModelDev& md, const
     const float* bias = md.b + (size_t)member * md.bmember + lm.boff_pairs;
     if constexpr (S::KSPLIT && R == 1) {  // the last hidden layer (index n_layers - 2) left its 13th tile as partial sums
         const float* const pi = part + ((md.n_layers - 2) & 1) * (kWaves * 64 * 4);
-        linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, -1, 1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl, 0, pi);
+        linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, HIPETS_KS_TRIPLE ? S::HIDC : -1, 1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl, 0, pi);
     } else {
         linear_op<R, S::ACT, S::OUTC, false, TL, S::LD, S::SPL_OUT, (HIPETS_UNROLL_K && MinWavesOf<R>::value == 1) ? S::HIDC : -1>(W, bias, lm, md.ld, false, md.activation, md.slope, in, nullptr, wave, lane, prof, nullptr, nullptr, &tl);
     }
@@ -1482,6 +1535,16 @@ __device__ __forceinline__ void rollout_normals4(int rid, int t, int blk, unsign
                                      (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32));
     box_muller(r4.x, r4.y, nrm[0], nrm[1]);
     box_muller(r4.z, r4.w, nrm[2], nrm[3]);
+}
+
+// termination_fns.hopper (:12-26) seen from ONE pair of state dims (d, d + 1): all finite, |dims 1..| < 100, height (dim 0) > 0.7,
+// |angle (dim 1)| < 0.2.  The row is unhealthy iff any of its pairs says so (fused tail lanes / the collecting threads of the
+// persistent DEVICE form, KSpec above).
+__device__ __forceinline__ bool hopper_pair_bad(const int d, const float vA, const float vB, const bool hasA, const bool hasB) {
+    bool bad = false;
+    if (hasA) bad = !isfinite(vA) || (d >= 1 ? !(fabsf(vA) < 100.0f) : !(vA > 0.7f));
+    if (hasB) bad = bad || !isfinite(vB) || !(fabsf(vB) < 100.0f) || (d == 0 && !(fabsf(vB) < 0.2f));
+    return bad;
 }
 
 struct RolloutSmem {
@@ -2048,6 +2111,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #endif
     int* const rows_a = sm.rowid;
     int* const rows_b = sm.pend + ROWS;
+    // fused hopper termination, persistent DEVICE form: per-row "the state this row arrived with is unhealthy" flags, raised by the
+    // collecting threads, consumed by the next tail (the fused instances never use sm.lrew: the learned reward stays in registers)
+    int* const hop_flags = reinterpret_cast<int*>(sm.lrew);
     // Collect the rows `rows` holds (published by their previous owners in step t_next - 1): every thread polls its (row slot, pair)
     // items as in the general form below, and the thread that receives a pair of state dims also writes them -- normalised exactly
     // like build_input_impl's f64 form -- into the next step's input image: no separate input pass, two barriers less per step.
@@ -2116,6 +2182,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                                 if (d == OM::kTrigDim) x0 = sv; else x1 = sv;
                                 dst[gs[q] * ld_in + lds_col(OM::kCosCol)] = live[q] ? (float)(((double)cv - sm.nmean[OM::kCosCol]) * sm.nstd[OM::kCosCol]) : 0.f;
                             }
+                        }
+                        if constexpr (S::TERM == HIPETS_TERM_HOPPER) {
+                            if (live[q] && hopper_pair_bad(d, v0, v1, true, d + 1 < md.obs_dim)) hop_flags[gs[q]] = 1;
                         }
                         const int c0 = OM::col(d), c1 = OM::col(d + 1);
                         sm.state[gs[q] * md.obs_dim + d] = v0;
@@ -2268,10 +2337,8 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 constexpr bool kAllDims = S::TERM == HIPETS_TERM_HOPPER;  // every lane judges its own dims; flags through LDS, folded in one step later (KSpec)
                 constexpr bool kRewLane = kLearnedRew && (S::TERM == HIPETS_TERM_NONE || kAllDims);  // the reward column's lane keeps the total (else: the lane with dims 0, 1)
                 if constexpr (kAllDims) {  // hopper: all dims finite, |dims 1..| < 100, height (dim 0) > 0.7, |angle (dim 1)| < 0.2
-                    bool bad = false;
-                    if (okA) bad = !isfinite(vA) || (d0 >= 1 ? !(fabsf(vA) < 100.0f) : !(vA > 0.7f));
-                    if (okB) bad = bad || !isfinite(vB) || !(fabsf(vB) < 100.0f) || (d0 == 0 && !(fabsf(vB) < 0.2f));
-                    if (bad) sm.pend[(t & 1) * ROWS + s] = 1;  // (every writer stores the same value; read after this step's barrier)
+                    // (persistent form: the row's next owner judges the dims it receives -- collect phases below)
+                    if (!persist && hopper_pair_bad(d0, vA, vB, okA, okB)) sm.pend[(t & 1) * ROWS + s] = 1;  // (every writer stores the same value; read after this step's barrier)
                 }
                 const int c_rew = kRewLane ? (md.obs_dim >> 3) : 0, g_rew = kRewLane ? ((md.obs_dim & 7) >> 1) : 0;
                 if (c == c_rew) {  // wave-uniform
@@ -2312,9 +2379,14 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         else rwd = reward_eval(st, actn_t + s * md.act_dim, 4, md.act_dim, S::REW, 0.f);
                         bool done = false;
                         if constexpr (kAllDims) {  // `terminated` up to and including step t - 1: that step's flag is complete since its barrier
-                            int* const flag = sm.pend + ((t & 1) ^ 1) * ROWS + s;
-                            trm = trm | (t > ra.t_begin ? *flag : 0);
-                            *flag = 0;  // (raised again in step t + 1 at the earliest: two barriers away)
+                            if (persist) {  // raised by the threads that collected this row's state (the state step t - 1 left)
+                                trm = trm | hop_flags[s];
+                                hop_flags[s] = 0;  // (raised again by the next collect phase: a barrier away)
+                            } else {
+                                int* const flag = sm.pend + ((t & 1) ^ 1) * ROWS + s;
+                                trm = trm | (t > ra.t_begin ? *flag : 0);
+                                *flag = 0;  // (raised again in step t + 1 at the earliest: two barriers away)
+                            }
                         } else {
                             done = term_eval(st, 4, S::TERM);
                         }
@@ -2643,6 +2715,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         if (!soft[q]) {
                             const int d = 2 * gv[q];
                             const float v0 = __uint_as_float(g[q][0]), v1 = __uint_as_float(g[q][2]);
+                            if constexpr (kFuse && S::TERM == HIPETS_TERM_HOPPER) {  // (rows of the padding hold zeros and no row id: never read)
+                                if (sm.rowid[gs[q]] >= 0 && hopper_pair_bad(d, v0, v1, true, d + 1 < md.obs_dim)) hop_flags[gs[q]] = 1;
+                            }
                             sm.state[gs[q] * md.obs_dim + d] = v0;
                             if (d + 1 < md.obs_dim) sm.state[gs[q] * md.obs_dim + d + 1] = v1;
                         } else if (src[q]) {
@@ -2666,9 +2741,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     if constexpr (kFuse && S::TERM == HIPETS_TERM_HOPPER) {
         // the fused all-dims termination folds step t's per-row flag into `terminated` one step later (tail_unit): the LAST step's
         // flag is still pending here.  It cannot change a return (model_env.py:186-188: the terminating step's reward counts), but
-        // sm.term is what a write-back would publish, so it is completed before anything reads it (complete since the step's barrier;
-        // the launcher admits these instances for whole-horizon launches only, rollout_inst.inc)
-        if (ra.t_end > ra.t_begin)
+        // sm.term is what the write-back publishes -- one launch per step in DEVICE mode: the next launch starts from it -- so it is
+        // completed before anything reads it (complete since the step's barrier)
+        if (ra.t_end > ra.t_begin && !persist)
             for (int s = tid; s < ROWS; s += kThreads) sm.term[s] |= sm.pend[((ra.t_end - 1) & 1) * ROWS + s];
     }
     for (int s = tid; s < ROWS; s += kThreads) {

@@ -40,12 +40,15 @@ __global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, in
     const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
     for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
     __syncthreads();
+    // blockIdx.z: slices of the workgroups whose slot is written here (every block computes ALL keys, then ranks its own slice: the
+    // rank count is O(nwg^2) -- ModelEnv.step on 100 000 rows is 6 250 workgroups, 1.1 ms in one block, round 5)
+    const int me0 = blockIdx.z * blockDim.x + threadIdx.x, me_step = blockDim.x * gridDim.z;
     if (iid) {
-        for (int me = threadIdx.x; me < nwg; me += blockDim.x)
+        for (int me = me0; me < nwg; me += me_step)
             sched[(size_t)t * nwg + me] = (int)(((keys[me] >> 32) * (unsigned long long)M) >> 32);
         return;
     }
-    for (int me = threadIdx.x; me < nwg; me += blockDim.x) {
+    for (int me = me0; me < nwg; me += me_step) {
         const unsigned long long kme = keys[me];
         int rank = 0;
         for (int i = 0; i < nwg; ++i) {

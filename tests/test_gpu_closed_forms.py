@@ -34,11 +34,11 @@ COMBOS = [
     ("humanoid_tanh", 9, 3, dict(termination="humanoid", activation="tanh"), {0: 1.05}),
     ("cartpole", 4, 1, dict(reward="cartpole", termination="cartpole"), {0: 2.3}),
     # the all-dims termination functions INSIDE the fused tail (hid 200, SiLU, learned reward: the pets_hopper and pets_inv_pendulum
-    # instances -- hopper's per-lane judgement with the flag folded in one step later, FAST mode; inverted_pendulum's four dims on one lane)
+    # instances -- hopper's per-lane judgement with the flag folded in one step later (persistent DEVICE form: by the row's next owner); inverted_pendulum's four dims on one lane)
     ("hopper_learned_fused", 11, 3, dict(termination="hopper", learned_rewards=True, reward=None, hid=200), {0: 0.76, 1: 0.0}),
     ("inv_pendulum_learned_fused", 4, 1, dict(termination="inverted_pendulum", learned_rewards=True, reward=None, hid=200), {1: 0.16}),
 ]
-FUSED_AT = {"hopper_learned_fused": (0, ("fast",)), "inv_pendulum_learned_fused": (3, ("fast", "device"))}  # forced row tiles, modes that run the fused instance
+FUSED_AT = {"hopper_learned_fused": (0, ("fast", "device")), "inv_pendulum_learned_fused": (3, ("fast", "device"))}  # forced row tiles, modes that run the fused instance
 IDS = [c[0] for c in COMBOS]
 
 

@@ -125,9 +125,13 @@ def test_device_mode_rejects_basic_ensemble_member_maps(engine):
 # beyond the chip: more logical workgroups than CUs, served in turns by the launched ones (420 at R = 3; 1 250 one-tile workgroups
 # of a small model; a ragged last turn)
 BIG = [(17, 6, 1000, 20, 5, dict(hid=200)), (5, 2, 4000, 5, 4, dict(hid=32)), (17, 6, 650, 20, 3, dict(hid=200))]
+# pets_hopper's fused DEVICE-mode instances (round 5): persistent form -- the row's next owner judges the dims it receives --, the same in
+# turns (2 600 rows per member = 163 one-tile / 82 two-tile workgroups per member on 256 CUs), and one launch per step (the launch's own
+# flag folded in before the write-back).  s0 sits next to the thresholds (_random_case): rows terminate at every step.
+HOPPER = [SIZES[18], (11, 3, 650, 20, 6, dict(ensemble_size=5, hid=200, learned_rewards=True, reward=None, termination="hopper"))]
 
 
-@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6], SIZES[11]] + BIG, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
+@pytest.mark.parametrize("case", [SIZES[0], SIZES[1], SIZES[5], SIZES[6], SIZES[11]] + BIG + HOPPER, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
 def test_persistent_and_per_step_launches_agree_bitwise(engine, case):
     """DEVICE-mode rollouts run as ONE launch with the rows handed over between workgroups through tagged granules (batches
     with more workgroups than CUs: every launched workgroup serves several logical ones per step); forbidding that (one launch

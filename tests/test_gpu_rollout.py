@@ -532,8 +532,8 @@ SHIPPED = [
     # the reward / termination lane sees are all there are ...
     ("pets_inv_pendulum", 4, 1, 480, 45, dict(learned_rewards=True, reward=None, termination="inverted_pendulum"), "fused"),
     # hopper (:12-26) tests eleven dims that sit in two column tiles, i.e. two waves: every lane judges its own, the flag goes through LDS
-    # and is folded in one step later -- where the row is still there: FAST instances; DEVICE-mode calls run the hidden-static instance
-    ("pets_hopper", 11, 3, 350, 30, dict(learned_rewards=True, reward=None, termination="hopper"), {"fast": "fused", "device": "hidden_static"}),
+    # and is folded in one step later; in the persistent DEVICE form the row's NEXT owner judges the dims it receives (round 5)
+    ("pets_hopper", 11, 3, 350, 30, dict(learned_rewards=True, reward=None, termination="hopper"), "fused"),
 ]
 
 
