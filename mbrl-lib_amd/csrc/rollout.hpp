@@ -675,6 +675,7 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                 asm volatile("s_nop 1");
                 mfma16x16x4(ks_b[j][s_], ks_a[j][s_], (s_ & 1) ? ks_o : ks_e);
             }
+        prof.mark(7);  // (profiling builds) the k-split share: its loads' round trip + 16 MFMAs
     }
     if constexpr (KCS > 0 && !kTriple) {
         constexpr int kEnd = KCS >= 2 ? ((KCS - 1) / 2) * 2 : 0;  // the loop below leaves kk at the smallest even number >= KCS - 2

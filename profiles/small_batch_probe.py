@@ -15,7 +15,7 @@ import hipets  # noqa: E402
 from conftest import to_spec  # noqa: E402
 from oracle import pets_oracle as po  # noqa: E402  (random weights only)
 
-PHASES = {0: "prologue", 8: "layer barrier", 9: "sample", 10: "reward+next input", 11: "k loop", 12: "dispatch", 13: "epilogue", 14: "set-up"}
+PHASES = {0: "prologue", 7: "k-split share (-DHIPETS_LEAN_PROF builds of the fused one-tile instances)", 8: "layer barrier", 9: "sample", 10: "reward+next input", 11: "k loop", 12: "dispatch", 13: "epilogue", 14: "set-up"}
 dev = torch.device("cuda:0")
 eng = hipets.get_engine(dev)
 out = {"lib": os.environ.get("HIPETS_LIB", "default")}

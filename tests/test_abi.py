@@ -180,6 +180,13 @@ def test_isa_scanner_sees_both_hazards_of_an_asm_mfma(tmp_path):
     # ... and a VALU write of an operand in the last slot before a forward branch into an MFMA
     n, found = scan("\tv_mov_b64_e32 v[32:33], s[70:71]\n\ts_cbranch_scc0 .LBB0_2\n\ts_nop 7\n\ts_nop 7\n.LBB0_2:\n" + mfma)
     assert len(found) == 1 and "writes a source" in found[0]
+    # an unconditional jump ends a fall-through path: the block behind it in the text is reached by its own branches only -- no
+    # finding for "MFMA; s_branch away; <label>: read of that register" unless a branch really carries the result there
+    away = mfma + "\ts_branch .LBB0_9\n.LBB0_3:\n\tv_add_f32_e32 v1, v30, v2\n.LBB0_9:\n\ts_nop 15\n\ts_endpgm\n"
+    n, found = scan(away)
+    assert n == 1 and found == []
+    n, found = scan("\ts_cbranch_scc0 .LBB0_4\n" + away.replace(".LBB0_9\n.LBB0_3:", ".LBB0_3\n.LBB0_3:"))  # the jump now leads INTO the read
+    assert len(found) == 1 and "reached by a branch to .LBB0_3" in found[0]
     # a compiler-issued MFMA (builtin, no asm markers) is the hazard recogniser's business, not the scan's
     n, found = scan("\tv_mov_b64_e32 v[32:33], s[70:71]\n\tv_mfma_f32_16x16x4_f32 v[30:33], v37, v53, v[30:33]\n")
     assert n == 0 and found == []
