@@ -30,8 +30,20 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
                                                  uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+        // one 32 x 32 -> 64 product each (v_mad_u64_u32: high and low half from ONE quarter-rate instruction; written as __umulhi and
+        // `*` the compiler issued v_mul_hi_u32 AND v_mul_lo_u32 -- 40 quarter-rate multiplies per call instead of 20, and the 10 rounds
+        // are half of a fused tail unit's VALU time)
+#ifndef HIPETS_PHILOX_MAD64
+#define HIPETS_PHILOX_MAD64 1
+#endif
+#if HIPETS_PHILOX_MAD64
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -203,9 +203,14 @@ struct NextOp {  // this wave's share of the op to prefetch for (wave-uniform)
 // cost 2.7x the 16-byte ones per byte, and a workgroup's polls queue behind its own stores).  The load is asynchronous:
 // pair_wait() is the s_waitcnt, tied to the destination registers so nothing reads them earlier.
 using u32x4g = __attribute__((ext_vector_type(4))) unsigned;
+// (s_nop 1 behind the store: a VMEM store of more than 8 bytes reads its data registers late, and on gfx940+ a VALU write of one
+// of them needs TWO wait states behind it.  The compiler keeps that distance for its own stores; inside an asm statement it does not
+// know there is a store.  Round 5: after an unrelated change the next instruction but one rewrote the first data register, and under
+// load -- two workgroups per CU -- quads of lanes published a scratch value instead of a state dim, or a corrupt tag that nobody could
+// ever match: returns off in the 5th digit, once a time-out.  __graft_entry__.scan_isa_hazards checks the emitted code for it now.)
 __device__ __forceinline__ void pair_store(unsigned long long* p, const unsigned v0, const unsigned v1, const unsigned tag) {
     const u32x4g d = {v0, tag, v1, tag};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
 __device__ __forceinline__ void pair_load_issue(u32x4g& d, const unsigned long long* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory");

@@ -39,7 +39,7 @@ def main():
                 print(f"[variant] {u}: {n} asm MFMAs, {len(found)} hazard finding(s), {len(scratch)} kernel(s) with scratch")
                 if found and not os.environ.get("HIPETS_ALLOW_ISA_HAZARDS"):
                     raise SystemExit("\n".join(found[:10]))
-            if f != os.path.basename(o):
+            if not (f.endswith(".o") and f[:-2] + ".hip" in units):  # -save-temps files; the recompiled units' objects stay
                 os.remove(path)
         objs.append(o)
     out = os.path.join(ROOT, "profiles", "variants", name + ".so")

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5: after the store-data hazard fix (pair_store + s_nop 1) -- persistent vs per-step sweep, tail sharing A/B at cfg2 and the
+# stock workloads, the rollout / device-mode / plan tests, bench
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out/r5j; mkdir -p $OUT
+run() { name=$1; shift; echo "== $name: $*" ; ( time timeout ${TMO:-1500} "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)"; }
+AB_POPS=650,660,700,500,1036 AB_R=0,2,3 run sweep python profiles/ab_sweep.py
+AB_REPS=3 run abdump python profiles/ab_dump.py $OUT/default.npz
+run variants_default python profiles/kernel_variants.py
+HIPETS_LIB=$PWD/profiles/variants/nots.so run variants_nots python profiles/kernel_variants.py
+run stock python profiles/stock_workloads.py --no-plans
+HIPETS_LIB=$PWD/profiles/variants/nots.so run stock_nots python profiles/stock_workloads.py --no-plans
+HIPETS_ORACLE_CACHE_OUT=$PWD/gpurun_out/oracle_cache run tests python -m pytest tests/test_gpu_rollout.py tests/test_gpu_closed_forms.py tests/test_gpu_device_mode.py tests/test_gpu_planning.py tests/test_gpu_plans_full_size.py -m gpu -q --maxfail=40 -p no:cacheprovider
+run bench python bench.py --no-cpu-baseline
+grep -h '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json
+echo done

@@ -187,6 +187,16 @@ def test_isa_scanner_sees_both_hazards_of_an_asm_mfma(tmp_path):
     assert n == 1 and found == []
     n, found = scan("\ts_cbranch_scc0 .LBB0_4\n" + away.replace(".LBB0_9\n.LBB0_3:", ".LBB0_3\n.LBB0_3:"))  # the jump now leads INTO the read
     assert len(found) == 1 and "reached by a branch to .LBB0_3" in found[0]
+    # (c) an asm VMEM store of more than 8 bytes reads its data registers late: a write to one of them needs two wait states behind it
+    store = "\t;;#ASMSTART\n\tglobal_store_dwordx4 v[8:9], v[4:7], off sc1\n\t;;#ASMEND\n"
+    n, found = scan(store + "\ts_or_b64 exec, exec, s[2:3]\n\tv_lshl_add_u32 v4, v168, 2, s50\n")  # the sequence round 5 found in an R = 2 instance
+    assert len(found) == 1 and "overwrites the data" in found[0]
+    n, found = scan(store.replace("sc1\n", "sc1\n\ts_nop 1\n") + "\tv_lshl_add_u32 v4, v168, 2, s50\n")
+    assert found == []
+    n, found = scan(store + "\tv_mov_b32_e32 v10, v4\n\tv_add_u32_e32 v11, v5, v6\n\tv_mov_b32_e32 v4, 0\n")  # reads are free; the write is 2 states away
+    assert found == []
+    n, found = scan("\tglobal_store_dwordx4 v[8:9], v[4:7], off\n\tv_mov_b32_e32 v4, 0\n")  # the compiler's own store: its hazard recogniser's business
+    assert found == []
     # a compiler-issued MFMA (builtin, no asm markers) is the hazard recogniser's business, not the scan's
     n, found = scan("\tv_mov_b64_e32 v[32:33], s[70:71]\n\tv_mfma_f32_16x16x4_f32 v[30:33], v37, v53, v[30:33]\n")
     assert n == 0 and found == []
