@@ -122,6 +122,7 @@ struct hipets_engine {
     DevBuf shard_values, gathered;
     // PlaNet latent model
     bool has_planet = false;
+    bool planet_static = false;  // the PlaNet model has conf/dynamics_model/planet.yaml's shapes: the STATIC kernel instance (planet_types.hpp)
     PlanetDev pd{};
     DevBuf planet_w, planet_b, planet_member, planet_ops;
     // fused plans: randomness mode of their rollouts, optional per-iteration trace
@@ -1707,6 +1708,7 @@ int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void*
     pd.b = e->planet_b.as<float>();
     pd.ops = e->planet_ops.as<PlanetOp>();
     e->pd = pd;
+    e->planet_static = planet_static_shape(pd, table);
     e->has_planet = true;
     return 0;
 }
@@ -1737,7 +1739,9 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     ra.trace_rewards = o->trace_rewards;
     const size_t lds = planet_smem_bytes(e->pd.ld);
     const int nwg = (int)((B + kTile - 1) / kTile);
-    HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st));
+    // (HIPETS_PLANET_GENERIC=1: the run-time generic instance whatever the shapes -- tests compare the two bit for bit)
+    const char* pg = std::getenv("HIPETS_PLANET_GENERIC");
+    HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st, e->planet_static && !(pg && pg[0] == '1')));
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
     return 0;

@@ -154,6 +154,6 @@ inline bool wide_model(const ModelDev& md) {
     return false;
 }
 
-hipError_t launch_planet_rollout(int grid, unsigned lds, int lds_max, const PlanetDev& pd, const PlanetArgs& ra, hipStream_t st);
+hipError_t launch_planet_rollout(int grid, unsigned lds, int lds_max, const PlanetDev& pd, const PlanetArgs& ra, hipStream_t st, bool static_shape);
 
 }  // namespace hipets

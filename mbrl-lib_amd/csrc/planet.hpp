@@ -26,6 +26,7 @@ __device__ __forceinline__ float sigmoid_hw(float x) { return __builtin_amdgcn_r
 // tanh(x) = 2 sigmoid(2x) - 1 (hardware exp2 / rcp, ~1e-7 absolute)
 __device__ __forceinline__ float tanh_hw(float x) { return 2.0f * sigmoid_hw(2.0f * x) - 1.0f; }
 
+template <bool STATIC>
 __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDev pd, const PlanetArgs ra) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* rows = reinterpret_cast<float*>(smem_raw);           // [16][ld]
@@ -123,8 +124,26 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
         // reward head (E -> B -> C -> D) | accumulate, next input
         for (int i = 0; i < kPlanetOps; ++i) {
             const PlanetOp op = ops[i];
-            linear_op<1, HIPETS_ACT_RELU>(pd.w + op.lm.woff, pd.b + op.lm.boff, op.lm, ld, op.relu != 0, HIPETS_ACT_RELU, 0.f, rows + op.in_off,
-                         rows + op.out_off, wave, lane, prof);
+            if constexpr (STATIC) {
+                // one shape-specialised instantiation per DISTINCT (column tiles, k chunks) pair: six for the eight ops
+                using PS = PlanetConfShape;
+                auto run = [&](auto cs, auto kcs) __attribute__((always_inline)) {
+                    linear_op<1, HIPETS_ACT_RELU, decltype(cs)::value, false, NoTail, PS::LD, false, decltype(kcs)::value, 4>(
+                        pd.w + op.lm.woff, pd.b + op.lm.boff, op.lm, PS::LD, op.relu != 0, HIPETS_ACT_RELU, 0.f, rows + op.in_off, rows + op.out_off, wave, lane, prof);
+                };
+                using std::integral_constant;
+                switch (i) {  // (wave-uniform)
+                    case 0: run(integral_constant<int, PS::kC[0]>{}, integral_constant<int, PS::kKC[0]>{}); break;
+                    case 1: case 2: run(integral_constant<int, PS::kC[1]>{}, integral_constant<int, PS::kKC[1]>{}); break;
+                    case 3: case 6: run(integral_constant<int, PS::kC[3]>{}, integral_constant<int, PS::kKC[3]>{}); break;
+                    case 4: run(integral_constant<int, PS::kC[4]>{}, integral_constant<int, PS::kKC[4]>{}); break;
+                    case 5: run(integral_constant<int, PS::kC[5]>{}, integral_constant<int, PS::kKC[5]>{}); break;
+                    default: run(integral_constant<int, PS::kC[7]>{}, integral_constant<int, PS::kKC[7]>{}); break;
+                }
+            } else {
+                linear_op<1, HIPETS_ACT_RELU>(pd.w + op.lm.woff, pd.b + op.lm.boff, op.lm, ld, op.relu != 0, HIPETS_ACT_RELU, 0.f, rows + op.in_off,
+                             rows + op.out_off, wave, lane, prof);
+            }
             if (op.post == PL_POST_NONE) continue;  // the next op touches other segments: same barrier interval
             __syncthreads();
             if (op.post == PL_POST_GRU) {

@@ -43,6 +43,24 @@ struct PlanetArgs {
     float* trace_rewards;  // optional [H,B]
 };
 
+// The shapes of conf/dynamics_model/planet.yaml (latent 30, belief 200, hidden 200, action 6 -- every planet_*.yaml override the
+// reference ships plans on them): per op (column tiles, k chunks) in execution order and the LDS row stride, as compile-time facts of
+// the STATIC instance (round 5).  Its ops run the shape-specialised one-tile path of the rollout kernel: per-wave share through one
+// branch, A-fragment reads with immediate offsets, fragment loads interleaved with the MFMAs and fetched two chunks ahead
+// (wave_gemm kTriple) -- the generic instance dispatches every op at run time through one shared copy of the GEMM code.
+// Same arithmetic per column (same k order, same tile -> wave deal): the two instances return the same bits.
+struct PlanetConfShape {
+    static constexpr int LD = 1736;
+    static constexpr int kC[kPlanetOps] = {13, 38, 38, 13, 4, 13, 13, 1};    // embed, hidden gates, input gates, prior 1 / 2, reward 1 / 2 / 3
+    static constexpr int kKC[kPlanetOps] = {3, 13, 13, 13, 13, 15, 13, 13};
+};
+inline bool planet_static_shape(const PlanetDev& pd, const PlanetOp* host_ops) {
+    if (pd.ld != PlanetConfShape::LD) return false;
+    for (int i = 0; i < kPlanetOps; ++i)
+        if (host_ops[i].lm.Np / kTile != PlanetConfShape::kC[i] || host_ops[i].lm.Kp / kKChunk != PlanetConfShape::kKC[i]) return false;
+    return true;
+}
+
 __host__ __device__ inline size_t planet_smem_bytes(int ld) {
     return (size_t)kTile * ld * 4 + 2 * kTile * 4 + sizeof(PlanetOp) * kPlanetOps;
 }

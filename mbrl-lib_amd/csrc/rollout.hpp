@@ -349,7 +349,8 @@ struct KsArgs {
     int wave;
 };
 
-// KS bit 0 (KSI): the input image's last k chunk is NOT in LDS -- it is rebuilt from ks->part_in; bit 1 (KSO): see above
+// KS bit 0 (KSI): the input image's last k chunk is NOT in LDS -- it is rebuilt from ks->part_in; bit 1 (KSO): see above;
+// bit 2: no k-split, only the one-tile k loop that fetches two chunks ahead (kTriple: ops with a static chunk count, planet.hpp)
 template <int R, int CT, int EX, int ACT, bool PRE = false, class TL = NoTail, int LD = -1, bool SPL = false, int KCS = -1, int KS = 0>
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* __restrict__ out, const int ld_rt,
                                           const float* __restrict__ W, const float* __restrict__ bias, const int KC_rt,
@@ -970,11 +971,11 @@ __device__ __forceinline__ void linear_op(const float* W, const float* bias, con
         if constexpr (std::is_same<TL, NoTail>::value) {
 #pragma unroll
             for (int p = 0; p < passes; ++p)
-                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
+                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS, (KS & 4)>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
         } else {  // with a fused tail inlined per unit the body is large: ONE copy, a real loop over the passes
 #pragma nounroll
             for (int p = 0; p < passes; ++p)
-                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
+                wave_gemm<R, kMaxCT, 0, ACT, false, TL, LD, SPL, KCS, (KS & 4)>(in, out, ld, W, bias, KC, lm.tail_steps, wave + kWaves * kMaxCT * p, ex, apply_act, activation, slope, lane, prof, nullptr, nullptr, tl, ldi);
         }
         const int c_first = wave + kWaves * kMaxCT * passes;
         // the nu leftover units are dealt round-robin: waves below nu % kWaves hold one more than the others

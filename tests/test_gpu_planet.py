@@ -64,6 +64,35 @@ def test_planet_rollout_matches_oracle(engine, latent, action, belief, hidden, p
     close(engine.planet_rollout(actions.to(DEV), latent0.to(DEV), belief0.to(DEV), P, sample=False), ref_det)
 
 
+@pytest.mark.parametrize("pop,P,H", [(1000, 1, 12), (37, 3, 4)])
+def test_planet_static_instance_equals_the_generic_kernel_bitwise(engine, pop, P, H):
+    """Models with conf/dynamics_model/planet.yaml's shapes (latent 30, belief 200, hidden 200, action 6: what every planet_*.yaml override
+    plans on) run a kernel instance with every op's tile / chunk counts and the LDS row stride as compile-time facts (planet.hpp STATIC,
+    round 5); HIPETS_PLANET_GENERIC=1 forces the run-time generic instance.  Same tile -> wave deal, same k order: the same bits, with
+    injected eps, in-kernel Philox draws and without sampling."""
+    pm = pl.make_synthetic_planet(30, 6, 200, 200, seed=11)
+    engine.planet_set_model(to_planet_spec(pm))
+    g = torch.Generator().manual_seed(5)
+    latent0, belief0 = (torch.randn(1, 30, generator=g) * 0.3).to(DEV), (torch.randn(1, 200, generator=g) * 0.3).to(DEV)
+    actions = (torch.rand(pop, H, 6, generator=g) * 2 - 1).to(DEV)
+    eps = torch.randn(H, pop * P, 30, generator=g).to(DEV)
+
+    def three():
+        return (engine.planet_rollout(actions, latent0, belief0, P, eps=eps).clone(), engine.planet_rollout(actions, latent0, belief0, P, seed=4, stream_id=2).clone(),
+                engine.planet_rollout(actions, latent0, belief0, P, sample=False).clone())
+
+    static = three()
+    os.environ["HIPETS_PLANET_GENERIC"] = "1"
+    try:
+        generic = three()
+    finally:
+        del os.environ["HIPETS_PLANET_GENERIC"]
+    for a, b in zip(static, generic):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    ref = pl.planet_rollout(pm, actions.cpu(), latent0.cpu(), belief0.cpu(), P, eps=eps.cpu())
+    close(static[0], ref)
+
+
 def test_planet_fast_mode_replayed_and_seeded(engine):
     """FAST mode draws eps with the rollout kernel's Philox streams: replay through the oracle with the exported normals."""
     pm = pl.make_synthetic_planet(12, 3, 48, 40, seed=9)
