@@ -582,8 +582,12 @@ def main():
         avg_ms = k_ms / max(n_l, 1)
         kernel_ms_per_plan = avg_ms * per_plan
         ach = cs * fl / (kernel_ms_per_plan * 1e-3) / 1e12
+        # which rollout-kernel instance each iteration's population runs, and with how many row tiles per workgroup (iCEM's decaying
+        # populations land on different geometries: hipets_kernel_class)
+        inst = [list(engine.kernel_class(r_, P_w, H_w, mode)) for r_ in sorted(set(rows), reverse=True)]
         return {"ms_per_plan": 1e3 * el, "value": cs / el, "unit": "candidate-steps/s", "candidate_steps_per_plan": cs,
-                "candidates_per_iteration": rows, "plans_timed": n_plans,
+                "candidates_per_iteration": rows, "kernel_instance_per_population_size": dict(zip(map(str, sorted(set(rows), reverse=True)), inst)),
+                "plans_timed": n_plans,
                 "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                              "kernel": "hipets::rollout_kernel", "launches_per_plan": per_plan, "avg_launch_ms": avg_ms,
                              "rollout_kernel_ms_per_plan": kernel_ms_per_plan, "flops_per_candidate_step": fl,

@@ -207,8 +207,10 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t num_particles, in
                         int32_t* row_tiles);
 
 /* FAST-mode randomness, exported so a FAST rollout can be replayed through a reference implementation:
- * schedule DEVICE int32 [H, n_workgroups] = member slot of workgroup w at step t (workgroup w owns particle
- * w % P of candidates [(w / P) * 16 * row_tiles, ...)); normals DEVICE f32 [H, B, out_dim] = the eps the kernel
+ * schedule DEVICE int32 [H, n_workgroups] = member slot of workgroup w at step t (the B = pop * P rows form one run,
+ * particle-major -- run index g = p * pop + c for particle p of candidate c, i.e. row c * P + p of the batch -- and
+ * workgroup w owns run indices [w * 16 * row_tiles, (w + 1) * 16 * row_tiles): n_workgroups = ceil(ceil(B / 16) /
+ * row_tiles)); normals DEVICE f32 [H, B, out_dim] = the eps the kernel
  * draws for (step, row, dim) with the same (seed, stream_id).                                                */
 int hipets_fast_schedule(hipets_engine* e, int32_t horizon, int32_t n_workgroups, uint64_t seed, uint64_t stream_id,
                          int32_t* schedule, void* stream);

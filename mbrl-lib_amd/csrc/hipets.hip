@@ -195,6 +195,9 @@ size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
 // member_schedule_kernel: blocks per (step, rollout) -- one per 256 workgroups whose slot they rank (rollout_helpers.hpp)
 inline unsigned schedule_slices(int nwg) { return (unsigned)std::max(1, std::min(64, (nwg + 255) / 256)); }
 
+// FAST-mode geometry: the B = pop x P rows are one run (rollout.hpp, prologue) of ceil(B / 16) row tiles, R per workgroup
+inline long long fast_tiles(long long pop, int P) { return (pop * P + kTile - 1) / kTile; }
+
 int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (waves w and w + 4 share SIMD w % 4)
     const int full = C / kWaves, rem = C % kWaves, nu = rem * R;
     int simd[4] = {0, 0, 0, 0};
@@ -205,7 +208,10 @@ int wave_units(int C, int R) {  // MFMA units per k-chunk of the busiest SIMD (w
 int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices, int forced, int horizon, bool wide, bool desync) {
     if (forced > 0) return forced;
     const int C = e->md.hidC;
-    const double a = 1.77 * (double)C / 13.0;  // the fixed part scales with the layer width like the units do
+    // the fixed part scales with the layer width like the units do.  WIDE instances (Humanoid-v4: 47 output column tiles, one workgroup per
+    // CU) carry their output layer and its tail in it: a round of two-tile workgroups costs 1.29 x a round of one-tile ones in FAST mode,
+    // 1.45 x in the turn-based DEVICE form (profiles/r5_cfg4p_iterations.json: the five population sizes of the cfg4' iCEM plan, both R)
+    const double a = (wide ? (desync ? 6.45 : 2.67) : 1.77) * (double)C / 13.0;
     int best = 1;
     double best_cost = 1e300;
     // bf16x3 arithmetic exists in shape-specialised instances only: among the R that have one (if any has: else the launch reports it)
@@ -298,9 +304,9 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
         return 0;
     }
     if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
-    const long long tiles = (pop + kTile - 1) / kTile;
-    const int R = choose_R(e, tiles, P, 0, H, wide_model(md) && n_env == 1, true);  // the fused plans' rollouts are lean calls unless batched
-    const int nwg = (int)((tiles + R - 1) / R) * P;
+    const long long tiles = fast_tiles(pop, P);
+    const int R = choose_R(e, tiles, 1, 0, H, wide_model(md) && n_env == 1, true);  // the fused plans' rollouts are lean calls unless batched
+    const int nwg = (int)((tiles + R - 1) / R);
     if (nwg > 8000) return 0;  // the rollout reports the error
     if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
     hipLaunchKernelGGL(member_schedule_kernel, dim3(H, iters, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->plan_schedule.as<int>(), nwg, md.M,
@@ -652,12 +658,12 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     if (!e || !e->has_model) return fail("engine has no model");
     if (pop < 1 || P < 1) return fail("bad pop/P");
     if (rows_per_group < -1 || rows_per_group > kMaxR) return fail("rows_per_group outside [-1, %d]", kMaxR);
-    const long long tiles = (pop + kTile - 1) / kTile;
+    const long long tiles = fast_tiles(pop, P);
     const bool wide = rows_per_group >= 0 && rows_per_group <= 2 && wide_model(e->md);  // a default call runs the WIDE instance there
-    const int R = choose_R(e, tiles, P, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide, true);
+    const int R = choose_R(e, tiles, 1, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide, true);
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
     const long long groups = (tiles + R - 1) / R;
-    if (n_workgroups) *n_workgroups = (int)(groups * P);
+    if (n_workgroups) *n_workgroups = (int)groups;
     if (row_tiles) *row_tiles = R;
     return 0;
 }
@@ -681,9 +687,9 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
                                           "Current batch size is %lld for %d models.", B, md.M);
         tiles = (B / domains + kTile - 1) / kTile;
         slices = domains;
-    } else {  // one slice of pop rows per particle
-        tiles = ((long long)pop + kTile - 1) / kTile;
-        slices = P;
+    } else {  // all B rows in one run
+        tiles = fast_tiles(pop, P);
+        slices = 1;
     }
     const bool wide = wide_model(md) && call_lean;
     const int R = choose_R(e, tiles, slices, 0, horizon, wide, mode == HIPETS_MODE_FAST);
@@ -904,7 +910,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;
         }
     } else if (o->mode == HIPETS_MODE_FAST) {
-        const long long tiles = (pop + kTile - 1) / kTile;
+        const long long tiles = fast_tiles(pop, P);
         ra.eps = o->fast_eps;
         ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
         // (a caller-sized member schedule follows hipets_fast_geometry: the default call's geometry -- the WIDE instance's where one
@@ -915,11 +921,11 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
                         "the wide-output instance's: size member_schedule with hipets_fast_geometry(rows_per_group = -1) and pass its row-tile "
                         "count as opts->rows_per_group");
         ra.wide_lds = wide ? 1 : 0;
-        const int R = choose_R(e, tiles, P, o->rows_per_group, H, wide, true);
+        const int R = choose_R(e, tiles, 1, o->rows_per_group, H, wide, true);
         const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
-        const int nwg = groups * P;
+        const int nwg = groups;
         if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d); shard the population", nwg);
         ra.groups = groups;
         if (md.propagation != HIPETS_PROP_EXPECTATION) {

@@ -1733,10 +1733,13 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     // ---- which rollout rows does this workgroup own; per-dimension constants into LDS -------------
     int domain = 0;
     if (fast) {
-        const int p = wg % ra.P, grp = wg / ra.P;
+        // the B = pop * P rows in ONE run, particle-major (run index g = p * pop + c), dealt ROWS at a time: ceil(ceil(B / 16) / R)
+        // workgroups, whatever pop is (until round 5 every particle's pop rows were dealt on their own: cfg4''s second iCEM iteration,
+        // pop 805 -> 51 tiles per particle, took 26 x 20 = 520 two-tile workgroups -- a third round on 256 CUs for 8 of them)
         for (int s = tid; s < ROWS; s += kThreads) {
-            const int c = grp * ROWS + s;
-            sm.rowid[s] = c < ra.pop ? c * ra.P + p : -1;
+            const int g = wg * ROWS + s;  // (<= 8000 workgroups x 64 rows)
+            const int p = g / ra.pop, c = g - p * ra.pop;
+            sm.rowid[s] = g < ra.B ? c * ra.P + p : -1;
         }
         if (!expectation)
             for (int t = tid; t < ra.H; t += kThreads) sm.sched[t] = ra.schedule[(size_t)t * gridDim.x + wg];

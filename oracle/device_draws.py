@@ -76,3 +76,16 @@ def member_schedule(H: int, nwg: int, M: int, seed: int, stream_id: int, fixed: 
             rank[np.lexsort((np.arange(nwg), keys))] = np.arange(nwg)  # ties broken by index, like the kernel's rank count
             out[t] = ((rank * M) // nwg).astype(np.int32)
     return out
+
+
+def fast_workgroups(B: int, row_tiles: int) -> int:
+    """Workgroups of a FAST rollout of B = pop * P rows with `row_tiles` 16-row tiles each (hipets_fast_geometry)."""
+    return -(-(-(-B // 16)) // row_tiles)
+
+
+def fast_row_workgroup(rows, P: int, row_tiles: int):
+    """Workgroup that owns each batch row of a FAST rollout; `rows` = arange(B), row = candidate * P + particle.  The rows form one
+    particle-major run -- run index particle * pop + candidate -- dealt 16 * row_tiles at a time (rollout.hpp, prologue;
+    include/hipets.h hipets_fast_schedule)."""
+    pop = len(rows) // P
+    return ((rows % P) * pop + rows // P) // (16 * row_tiles)

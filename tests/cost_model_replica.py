@@ -15,12 +15,12 @@ def wave_units(C, R):
     return max(simd)
 
 
-def cost(tiles, slices, R, lean, desync, C=13):
-    a = 1.77 * C / 13.0
+def cost(tiles, slices, R, lean, desync, C=13, wide=False):
+    a = ((6.45 if desync else 2.67) if wide else 1.77) * C / 13.0
     groups = (tiles + R - 1) // R
     nwg = groups * slices
     n = (nwg + NUM_CU - 1) // NUM_CU
-    co = 2 if R <= 2 else 1
+    co = 2 if (R <= 2 and not wide) else 1
     u = wave_units(C, R)
     u_pair = C * R / 4.0 if (co == 2 and desync) else u
     full, rem = divmod(n, co)
@@ -28,13 +28,14 @@ def cost(tiles, slices, R, lean, desync, C=13):
     return c * (1.0 if lean else 1.08)
 
 
-def choose_r(pop, P, members, mode, lean_rs, rs=(1, 2, 3, 4)):
-    """mode 'fast': one slice of pop rows per particle; 'device': one slice of pop P / members rows per member."""
+def choose_r(pop, P, members, mode, lean_rs, rs=(1, 2, 3, 4), wide=False):
+    """mode 'fast': the pop P rows in one run (since round 5; before: one slice of pop rows per particle -- the same choice for every
+    workload below); 'device': one slice of pop P / members rows per member.  wide: the Humanoid-v4 instances (rs = (1, 2))."""
     fast = mode == "fast"
-    tiles, slices = ((pop + 15) // 16, P) if fast else ((pop * P // members + 15) // 16, members)
+    tiles, slices = ((pop * P + 15) // 16, 1) if fast else ((pop * P // members + 15) // 16, members)
     best, best_cost = rs[0], float("inf")
     for R in rs:
-        c = cost(tiles, slices, R, R in lean_rs, fast)
+        c = cost(tiles, slices, R, R in lean_rs, fast, wide=wide)
         if c < best_cost - 1e-9:
             best, best_cost = R, c
     return best

@@ -9,6 +9,7 @@ import hipets
 from conftest import to_spec
 from hipets.planning import _BoundObjective
 from oracle import pets_oracle as po
+from oracle import device_draws
 from test_gpu_plans_full_size import check_values, elites_agree
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +27,7 @@ def batched_replay(engine, om, s0, P, H, seed):
         sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
         eps = engine.fast_normals(H, pop * P, seed, stream).cpu()
         rows = torch.arange(pop * P)
-        wg = ((rows // P) // (16 * r)) * P + rows % P
+        wg = device_draws.fast_row_workgroup(rows, P, r)
         members = torch.stack([sched[t][wg].long() for t in range(H)])
         out = []
         for e_ in range(n_env):

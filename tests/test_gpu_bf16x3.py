@@ -10,6 +10,7 @@ import hipets
 from conftest import to_spec
 from hipets.planning import _BoundObjective
 from oracle import pets_oracle as po
+from oracle import device_draws
 from test_gpu_rollout import SIZES, _random_case, assert_returns_close
 
 pytestmark = pytest.mark.gpu
@@ -27,19 +28,29 @@ def test_bf16x3_rollouts_replayed_through_the_oracle(engine, case, mode):
     out = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=seed, stream_id=sid)
     eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
     nwg, r = engine.fast_geometry(pop, P, H)  # (of the bf16x3 model: the row-tile counts that have a bf16x3 instance)
+    tr = {}
     if mode == "device":
-        ref = po.rollout(om, actions, s0, P, perms=engine.device_perms(H, pop * P, seed, sid).cpu(), eps=eps)
+        ref = po.rollout(om, actions, s0, P, perms=engine.device_perms(H, pop * P, seed, sid).cpu(), eps=eps, trace=tr)
     else:
         sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
         rows = torch.arange(pop * P)
-        wg = ((rows // P) // (16 * r)) * P + rows % P
-        ref = po.rollout(om, actions, s0, P, members=torch.stack([sched[t][wg].long() for t in range(H)]), eps=eps)
-    assert_returns_close(out, ref)  # T2, the fp32 mode's own tolerance
+        wg = device_draws.fast_row_workgroup(rows, P, r)
+        ref = po.rollout(om, actions, s0, P, members=torch.stack([sched[t][wg].long() for t in range(H)]), eps=eps, trace=tr)
+    keep = torch.ones(pop, dtype=torch.bool)
+    if om.termination == "humanoid":
+        # a termination threshold is a discontinuity: a row whose height lands within an ulp of 1.0 / 2.0 (termination_fns.py:88-95) ends
+        # on one side in the oracle and may end on the other on the device.  Round 5's FAST row dealing put such a row into this case
+        # (candidate 567, step 1: z = 2.0000002, re-derived on the CPU from oracle/device_draws.py); candidates with a row within 2e-5 of a
+        # threshold are not compared -- a handful of 1036 (20 720 rows x 4 steps over a range of ~4)
+        z = torch.stack([n[:, 0] for n in tr["next_obs"]])
+        keep = ~(torch.minimum((z - 1.0).abs(), (z - 2.0).abs()) < 2e-5).any(0).view(pop, P).any(1)
+        assert int((~keep).sum()) <= 8
+    assert_returns_close(out.cpu()[keep], ref[keep])  # T2, the fp32 mode's own tolerance
     # against the fp32-MFMA kernel on the same draws (FAST: and the same geometry -- the member schedule is per workgroup, and the fp32
     # model is free to pick another row-tile count): the two arithmetic modes agree far inside T2
     engine.set_model(to_spec(om, obs, act))
     f32 = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=seed, stream_id=sid, rows_per_group=r if mode == "fast" else 0)
-    err = ((out - f32).abs() / torch.clamp(f32.abs(), min=1.0)).max().item()
+    err = ((out - f32).abs() / torch.clamp(f32.abs(), min=1.0)).cpu()[keep].max().item()
     assert err < 2e-5, err
 
 

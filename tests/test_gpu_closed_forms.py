@@ -17,6 +17,7 @@ import torch
 
 from conftest import to_spec
 from oracle import pets_oracle as po
+from oracle import device_draws
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -76,7 +77,7 @@ def fast_members(engine, pop, P, H, seed, sid, fixed=False, rows_per_group=0):
     nwg, r = engine.fast_geometry(pop, P, H, rows_per_group)
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     rows = torch.arange(pop * P)
-    wg = ((rows // P) // (16 * r)) * P + rows % P
+    wg = device_draws.fast_row_workgroup(rows, P, r)
     return torch.stack([sched[0 if fixed else t][wg].long() for t in range(H)])
 
 

@@ -31,3 +31,12 @@ def test_replica_equals_the_library(engine, case, mode):
     cls, r = engine.kernel_class(pop, 20, H, mode)
     assert r == cm.choose_r(pop, 20, 5, mode, lean)
     assert cls == ("fused" if r in lean else "hidden_static")
+
+
+@pytest.mark.parametrize("mode", ["fast", "device"])
+@pytest.mark.parametrize("pop", [1036, 805, 630, 497, 358])  # the cfg4' iCEM plan's five population sizes (profiles/r5_cfg4p_iterations.json)
+def test_wide_instances_follow_the_replica_too(engine, pop, mode):
+    om = po.make_synthetic_model(376, 17, hid=200, seed=0, ensemble_size=7, elite=[0, 1, 2, 3, 4], termination="humanoid")
+    engine.set_model(to_spec(om, 376, 17))
+    cls, r = engine.kernel_class(pop, 20, 40, mode)
+    assert cls == "wide" and r == cm.choose_r(pop, 20, 5, mode, {1, 2}, rs=(1, 2), wide=True) == 2

@@ -12,6 +12,7 @@ import torch
 import hipets
 from conftest import GOLDEN, to_spec
 from oracle import pets_oracle as po
+from oracle import device_draws
 from oracle.golden_io import load_case
 
 pytestmark = pytest.mark.gpu
@@ -350,7 +351,7 @@ def test_batched_rollout_replayed_through_oracle_per_environment(engine):
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
     rows = torch.arange(pop * P)
-    wg = ((rows // P) // (16 * r)) * P + rows % P
+    wg = device_draws.fast_row_workgroup(rows, P, r)
     members = torch.stack([sched[t][wg].long() for t in range(H)])
     for e_ in range(n_env):
         sl = slice(e_ * pop_env * P, (e_ + 1) * pop_env * P)

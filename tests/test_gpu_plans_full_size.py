@@ -19,6 +19,7 @@ import oracle_cache as oc
 from conftest import to_spec
 from hipets.planning import _BoundObjective
 from oracle import pets_oracle as po
+from oracle import device_draws
 from oracle.make_golden import FULL_CASES, full_case_agent_cfg, weights_checksum
 from test_oracle_full_size import load_full
 
@@ -54,7 +55,7 @@ def replay_rollout(engine, om, s0, P, H, mode, seed):
             nwg, r = engine.fast_geometry(pop, P, H)
             sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
             rows = torch.arange(B)
-            wg = ((rows // P) // (16 * r)) * P + rows % P
+            wg = device_draws.fast_row_workgroup(rows, P, r)
             geometry = (nwg, r, sched)
         # the draws are functions of (seed, stream) -- counter-based; the population is what the engine recorded: the oracle's answer
         # for exactly these bytes is memoised (tests/oracle_cache.py); a kernel change that moves a population by one ulp recomputes

@@ -14,6 +14,7 @@ import hipets
 import oracle_cache as oc
 from conftest import GOLDEN, to_spec
 from oracle import pets_oracle as po
+from oracle import device_draws
 from oracle.golden_io import load_case
 
 pytestmark = pytest.mark.gpu
@@ -139,7 +140,7 @@ def test_fast_mode_replayed_through_oracle(engine, case):
     out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid)
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     rows = torch.arange(pop * P)
-    wg = ((rows // P) // (16 * r)) * P + rows % P
+    wg = device_draws.fast_row_workgroup(rows, P, r)
     members = torch.stack([sched[0 if om.propagation == "fixed_model" else t][wg].long() for t in range(H)])
     # eps = the library's Philox normals of (seed, stream): a function of the counters, exported only when the oracle has to run
     ref = oc.cached("rollout_sizes", ["fast", *oc.model_parts(om), actions, s0, P, members, ("philox", seed, sid)],
@@ -348,7 +349,7 @@ def test_basic_ensemble_per_member_logvar_bounds_and_fast_mode(engine):
     sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     assert sched.min() >= 0 and sched.max() < E
     rows = torch.arange(B)
-    wg = ((rows // P) // (16 * r)) * P + rows % P
+    wg = device_draws.fast_row_workgroup(rows, P, r)
     fast_members = torch.stack([sched[t][wg].long() for t in range(H)])
     assert_returns_close(out_f, oracle(fast_members, engine.fast_normals(H, B, seed, sid).cpu()))
     # batch sizes that are not multiples of the ensemble size are accepted (no GaussianMLP batch rule)

@@ -95,9 +95,9 @@ def test_fast_entries_replayed_with_cpu_restatements_of_the_draws(case):
     rows = torch.arange(B)
     hit = None
     for r in (1, 2, 3, 4):  # the row-tile count is the engine's choice (hipets_fast_geometry): the recorded entry names it through its key
-        nwg = ((pop + 16 * r - 1) // (16 * r)) * P
+        nwg = device_draws.fast_workgroups(B, r)
         sched = torch.from_numpy(device_draws.member_schedule(1 if fixed else H, nwg, M, seed, sid, fixed=fixed, iid=om.ensemble_kind == "basic_ensemble"))
-        wg = ((rows // P) // (16 * r)) * P + rows % P
+        wg = device_draws.fast_row_workgroup(rows, P, r)
         members = torch.stack([sched[0 if fixed else t][wg].long() for t in range(H)])
         key = oc._digest(["fast", *oc.model_parts(om), actions, s0, P, members, ("philox", seed, sid)])
         if key in g.data:
