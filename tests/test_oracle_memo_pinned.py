@@ -107,3 +107,20 @@ def test_fast_entries_replayed_with_cpu_restatements_of_the_draws(case):
     key, members = hit
     fresh = po.rollout(om, actions, s0, P, members=members, eps=_cpu_eps(om, H, B, seed, sid))
     _close(fresh, g.data[key], om, P)
+
+
+def test_fast_row_dealing_restatement_is_the_headers_statement():
+    """include/hipets.h (hipets_fast_schedule): the B = pop * P rows form one particle-major run, run index g = p * pop + c for batch row
+    c * P + p, and workgroup w owns run indices [w * 16 * row_tiles, (w + 1) * 16 * row_tiles) -- spelled out with loops here and compared
+    with oracle/device_draws.fast_row_workgroup / fast_workgroups, which every FAST replay of the GPU suite uses."""
+    for pop, P, r in [(805, 20, 2), (500, 20, 3), (100, 5, 1), (7, 3, 1), (16, 1, 1), (17, 1, 4), (1036, 20, 2)]:
+        B = pop * P
+        owner = np.full(B, -1)
+        for g in range(B):
+            p, c = divmod(g, pop)
+            owner[c * P + p] = g // (16 * r)
+        assert (owner >= 0).all()
+        assert np.array_equal(device_draws.fast_row_workgroup(np.arange(B), P, r), owner)
+        assert np.array_equal(device_draws.fast_row_workgroup(torch.arange(B), P, r).numpy(), owner)
+        assert device_draws.fast_workgroups(B, r) == owner.max() + 1 == -(-(-(-B // 16)) // r)
+    assert device_draws.fast_workgroups(805 * 20, 2) == 504  # (per particle it was 26 x 20 = 520: a third round on 256 CUs)
