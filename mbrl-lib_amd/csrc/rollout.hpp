@@ -1977,6 +1977,46 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         // SIMD -- spilt one VGPR to scratch with four sinf / cosf-bearing elements held for one store)
         constexpr bool kByGroup = HIPETS_INPUT_BY_GROUP && !kB3 && (PLAIN || !kLean);
         const float* actn_t = sm.actn + (t & 1) * n_act;
+#ifndef HIPETS_INPUT_BATCHED
+#define HIPETS_INPUT_BATCHED 1
+#endif
+        if constexpr (HIPETS_INPUT_BATCHED && kByGroup && PLAIN && NORM != HIPETS_NORM_F32) {
+            // Round 5 (step trace of the turn-based DEVICE form, profiles/r5_turn_trace.json: 8.3 us per turn for cfg4''s 32 rows x 400
+            // columns = 20 k cycles for 12.5 items per thread): the loop below is a chain of LDS round trips -- row id, then the value
+            // (from the state or from the actions, behind a branch), then the two normaliser doubles, element after element.  Here an
+            // item's twelve LDS reads are independent of each other (the value's source is a selected ADDRESS, not a branch) and issued
+            // together, the (row, quad) of an item follows from the previous item's by addition; same arithmetic per element.
+            const int d_s = kThreads / kq, d_c = kThreads - d_s * kq;
+            int s = tid / kq, cq = tid - s * kq;
+            for (int i = tid; i < ROWS * kq; i += kThreads) {
+                const bool valid = sm.rowid[s] >= 0;
+                float xv[4];
+                double nm[4], ns[4];
+                bool inb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = ((cq >> 2) << 4) + 4 * q + (cq & 3);
+                    const int cc = min(c, md.in_dim - 1);
+                    const float* src = cc < md.obs_in ? sm.state + s * md.obs_dim + cc : actn_t + s * md.act_dim + (cc - md.obs_in);
+                    xv[q] = *src;
+                    inb[q] = c < md.in_dim;
+                    if constexpr (NORM == HIPETS_NORM_F64) { nm[q] = sm.nmean[cc]; ns[q] = sm.nstd[cc]; }
+                }
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = xv[q];
+                    if constexpr (NORM == HIPETS_NORM_F64) x = (float)(((double)x - nm[q]) * ns[q]);
+                    v[q] = (inb[q] && valid) ? x : 0.f;
+                }
+                HIPETS_BOUND(s >= 0 && s < ROWS && 4 * cq + 3 < ld_in);
+                *reinterpret_cast<f32x4*>(dst + s * ld_in + 4 * cq) = v;
+                s += d_s;
+                cq += d_c;
+                if (cq >= kq) { cq -= kq; ++s; }
+            }
+            return;
+        }
         for (int i = tid; i < ROWS * kq; i += kThreads) {
             const int s = i / kq, cq = i % kq;
             const bool valid = sm.rowid[s] >= 0;

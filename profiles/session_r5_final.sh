@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/r5_final; mkdir -p $OUT
 run() { name=$1; shift; echo "== $name: $*" ; ( time timeout ${TMO:-1500} "$@" ) > $OUT/$name.log 2>&1; echo "   rc=$? $(tail -n 3 $OUT/$name.log | tr '\n' ' ' | cut -c1-300)"; }
 run smoke python -c "import __graft_entry__ as g; g.smoke()"
+if [ -z "${SKIP_MEMO_FIX:-}" ]; then  # (done once, in the session of commit c54828b; later runs of this script: SKIP_MEMO_FIX=1)
 HIPETS_ORACLE_CACHE=0 HIPETS_ORACLE_CACHE_OUT=$PWD/gpurun_out/oracle_cache_fix run memo_fix python -m pytest tests/test_gpu_plans_full_size.py -q -p no:cacheprovider -k "test_fused_cem_plan_cfg2_replayed_through_oracle and stock_halfcheetah and fast"
 python - <<'PY'
 import numpy as np, os
@@ -24,6 +25,7 @@ os.makedirs("gpurun_out/oracle_cache", exist_ok=True)
 for p in (dst, "gpurun_out/oracle_cache/plans_full_size.npz"):
     np.savez_compressed(p, **data)
 PY
+fi
 HIPETS_ORACLE_CACHE_OUT=$PWD/gpurun_out/oracle_cache run tests python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider --durations=10
 run bench python bench.py
 grep -h '"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json
