@@ -1,4 +1,4 @@
-"""The bench line the repository ships (profiles/r4_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
+"""The bench line the repository ships (profiles/r5_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
 contract and is internally consistent: the roofline block follows from the algorithmic FLOP count and the measured launch
 time, `value` from the plan time, the metric / workload are BASELINE.json's.  (CPU test: reads committed files only.)"""
 import json
@@ -10,7 +10,7 @@ from conftest import ROOT
 
 
 def _line():
-    return json.load(open(os.path.join(ROOT, "profiles", "r4_bench_line.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
 
 
 def test_contract_keys_and_types():
@@ -46,11 +46,11 @@ def test_roofline_block_is_consistent():
 
 
 def test_rocprof_summary_agrees_with_the_live_measurement():
-    """profiles/r4_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
+    """profiles/r5_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
     import csv
 
     r = _line()["roofline"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_kernel_stats_device.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_kernel_stats_device.csv"))))
     roll = [x for x in rows if "rollout_kernel" in x["Name"]]
     assert roll, "no rollout kernel in the committed rocprofv3 statistics"
     avg_ms = float(roll[0]["AverageNs"]) * 1e-6
@@ -131,16 +131,18 @@ def test_bench_constants_are_the_baseline_config():
 
 
 def test_pmc_summary_counts_the_kernel_this_repository_ships():
-    """profiles/r{2,3}_rollout_pmc.json: SQ_INSTS_MFMA per launch equals the count derived from the kernel's structure -- 2178
+    """profiles/r{2..5}_rollout_pmc.json: SQ_INSTS_MFMA per launch equals the count derived from the kernel's structure -- 2178
     v_mfma_f32_16x16x4_f32 per row-tile-step at cfg2 (input 13x6 + 3 x 13x50 + output 3x50 column-tile k-steps) x row tiles x
     horizon: 210 workgroups x 3 tiles in DEVICE mode (5 members x 42 groups), 220 x 3 in FAST mode (11 candidate groups x 20
     particles).  A counter file from another kernel or another workload would not reproduce these integers."""
     per_tile_step = 13 * 6 + 3 * 13 * 50 + 3 * 50
     assert per_tile_step == 2178
-    for tag in ("r2", "r3", "r4"):  # round 3's fused output layer issues the same MFMAs (another pack of the same 3 column tiles)
+    for tag in ("r2", "r3", "r4", "r5"):  # round 3's fused output layer issues the same MFMAs (another pack of the same 3 column tiles)
         pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_rollout_pmc.json")))
+        # round 5: FAST rows are dealt as one run -- ceil(625 row tiles / 3) = 209 workgroups instead of 11 x 20
+        fast_wgs = 209 if tag == "r5" else 11 * 20
         assert pmc["device"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (5 * 42 * 3) * 30, tag
-        assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (11 * 20 * 3) * 30, tag
+        assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (fast_wgs * 3) * 30, tag
         for mode in ("device", "fast"):
             d = pmc[mode]["derived"]
             assert 0.4 < d["mfma_pipe_busy_frac_on_active_simds"] < 1.0
@@ -165,3 +167,24 @@ def test_wide_instance_pmc_counts_the_cfg4p_kernel():
     assert d["algorithmic_flops_per_launch"] == 2 * (393 * 200 + 3 * 200 * 200 + 200 * 752) * 1036 * 20 * 40
     assert d["frac_of_fp32_peak"] == pytest.approx(d["algorithmic_flops_per_launch"] / (d["avg_ns"] * 1e-9) / 157.3e12, rel=1e-9)
     assert d["frac_of_fp32_peak"] > 0.40  # the round-2 verdict's target for this configuration
+
+
+def test_round5_blocks_model_env_step_planet_and_instances_per_population_size():
+    """The blocks added in round 5: `model_env_step` (100 000 rows through hipets_step, priced with the same per-row FLOP count as a
+    candidate-step), `planet` (conf-size latent planner, 10-iteration CEM) -- each with its own roofline object and live launch
+    durations -- and, for the iCEM plans, which kernel instance / row-tile count every population size of the plan runs."""
+    d = _line()
+    st = d["model_env_step"]
+    for mode in ("device", "fast"):
+        r = st[mode]["roofline"]
+        assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0 < r["frac"] < 1
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+        assert st[mode]["value"] > 1e8 and st[mode]["ms_per_call"] >= r["avg_launch_ms"]
+    pl = d["planet"]
+    assert 0 < pl["roofline"]["frac"] < 1 and pl["ms_per_plan"] >= 10 * pl["roofline"]["avg_launch_ms"] * 0.99
+    icem = d["other_configs"]["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"]
+    for mode in ("device", "fast"):
+        inst = icem[mode]["kernel_instance_per_population_size"]
+        assert sorted(map(int, inst), reverse=True) == [1036, 805, 630, 497, 358]
+        assert all(v == ["wide", 2] for v in inst.values())
+    assert icem["fast"]["roofline"]["frac"] > 0.43  # the round-4 verdict's plan-level target for FAST mode
