@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HIPETS_ABI_VERSION 5
+#define HIPETS_ABI_VERSION 6
 #define HIPETS_MAX_LAYERS 8
 
 typedef struct hipets_engine hipets_engine;
@@ -125,7 +125,8 @@ typedef struct {
     /* FAST and DEVICE modes: counter-based RNG                                                   */
     uint64_t seed;
     uint64_t stream_id;      /* e.g. plan counter * iterations + iteration                        */
-    const int32_t* member_schedule; /* DEVICE [H, n_workgroups] optional override (testing)       */
+    const int32_t* member_schedule; /* DEVICE [H, n_workgroups] optional override of the FAST-mode */
+                             /*   member draws (testing; TS-infinity ModelEnv.step); see member_schedule_len */
     const float* fast_eps;   /* DEVICE [H,B,out_dim] optional override of the Philox normals      */
     /* optional debug taps (DEVICE, may be NULL)                                                  */
     float* trace_next_obs;   /* [H,B,obs_dim]                                                     */
@@ -140,13 +141,21 @@ typedef struct {
                              /*   BASIC_ENSEMBLE (randint maps, basic_ensemble.py:122-129); for GAUSSIAN_MLP it          */
                              /*   expresses mbrl.util.math.propagate_from_indices (util/math.py:180-196): any            */
                              /*   row -> member assignment, no batch % members rule                                      */
-    int32_t n_env;           /* FAST batched planning: the pop candidates are n_env groups of  */
-                             /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one */
+    int32_t n_env;           /* FAST / DEVICE batched planning: the pop candidates are n_env groups of */
+                             /*   pop / n_env, group g starts from s0[g] (s0 is then HOST [n_env, obs_dim]); 0/1 = one.     */
+                             /*   DEVICE: ONE balanced permutation per step over the rows of all environments               */
     int32_t generic_kernel;  /* 1 = only the fully generic kernel instance.  (The library also instantiates the rollout     */
                              /*   kernel (a) for hidden widths of 193..208 -- the reference's default 200 -- with the hidden  */
                              /*   layers' shape as a compile-time fact and everything else generic, and (b) for the BASELINE */
                              /*   shapes with all layer shapes / reward / termination fns as compile-time facts; same        */
                              /*   arithmetic -- tests compare them bit for bit.)  2 = (a) allowed, (b) not                   */
+    /* ABI v6 */
+    int32_t member_schedule_len; /* entries of member_schedule (horizon x n_workgroups of hipets_fast_geometry); 0 = not stated.  */
+                             /*   A stated length that does not match the call's geometry fails the call instead of reading   */
+                             /*   the schedule with another stride (the geometry of FAST calls changed in ABI v5 -> v6)       */
+    uint64_t perm_stream_id; /* hipets_step, DEVICE mode, fixed_model propagation: stream of the TS-infinity permutation (the     */
+                             /*   stream of the rollout's reset: model.py:404-407) while stream_id -- the step's -- keys the eps; */
+                             /*   0 = stream_id                                                                                   */
 } hipets_rollout_opts;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -174,8 +183,9 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
  * One transition for B independent rows: obs DEVICE [B,obs_dim], actions DEVICE [B,act_dim] ->
  * next_obs DEVICE [B,obs_dim], rewards DEVICE [B] f32, dones DEVICE [B] uint8.  opts as for hipets_rollout with
  * horizon 1 and one particle per row: EXACT takes perms [B] (one torch.randperm, or the fixed_model indices) and eps
- * [1,B,out_dim] (NULL => the deterministic mean, i.e. ModelEnv.step(sample=False)); FAST draws both in-kernel from
- * (seed, stream_id); set opts->no_sample for the deterministic mean in FAST mode.                                  */
+ * [1,B,out_dim] (NULL => the deterministic mean, i.e. ModelEnv.step(sample=False)); DEVICE (the reference's per-row balanced
+ * shuffle, gaussian_mlp.py:203-205) and FAST (one member per workgroup of 16 R consecutive rows) draw both in-kernel from
+ * (seed, stream_id); set opts->no_sample for the deterministic mean.  DEVICE + fixed_model: see opts->perm_stream_id.          */
 int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_t batch, const hipets_rollout_opts* opts,
                 float* next_obs, float* rewards, uint8_t* dones, void* stream);
 
@@ -190,7 +200,8 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, i
 
 /* Which instance of the rollout kernel a DEFAULT call (hipets_rollout / the fused plans with in-kernel randomness, no injected
  * eps, no traces) of this size runs on the engine's model, and with how many row tiles per workgroup.  mode: HIPETS_MODE_FAST or
- * HIPETS_MODE_DEVICE.  The instances compute the same arithmetic (the GPU suite compares them bit for bit); they differ in how
+ * HIPETS_MODE_DEVICE.  rows_per_group: 0 = the library's own choice (what a default call does); 1..4 = the answer for a call that
+ * forces this row-tile count through opts->rows_per_group (ABI v6).  The instances compute the same arithmetic (the GPU suite compares them bit for bit); they differ in how
  * much of the model's shape is a compile-time fact:
  *   GENERIC        everything decided at run time (any widths, activations, propagation, normaliser)
  *   HIDDEN_STATIC  SiLU models whose hidden layers are 193..208 wide -- the reference's default 200
@@ -203,15 +214,21 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t num_particles, i
  *   WIDE           FUSED for output layers wider than 8 column tiles (Humanoid-v4)
  * Diagnostic only -- nothing needs to call it; a profile (rocprofv3 --kernel-trace) shows the same thing as a kernel name.      */
 enum { HIPETS_KERNEL_GENERIC = 0, HIPETS_KERNEL_HIDDEN_STATIC = 1, HIPETS_KERNEL_FUSED = 2, HIPETS_KERNEL_WIDE = 3 };
-int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t mode, int32_t* kernel_class,
-                        int32_t* row_tiles);
+int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t num_particles, int32_t horizon, int32_t mode, int32_t rows_per_group,
+                        int32_t* kernel_class, int32_t* row_tiles);
 
 /* FAST-mode randomness, exported so a FAST rollout can be replayed through a reference implementation:
  * schedule DEVICE int32 [H, n_workgroups] = member slot of workgroup w at step t (the B = pop * P rows form one run,
  * particle-major -- run index g = p * pop + c for particle p of candidate c, i.e. row c * P + p of the batch -- and
  * workgroup w owns run indices [w * 16 * row_tiles, (w + 1) * 16 * row_tiles): n_workgroups = ceil(ceil(B / 16) /
- * row_tiles)); normals DEVICE f32 [H, B, out_dim] = the eps the kernel
- * draws for (step, row, dim) with the same (seed, stream_id).                                                */
+ * row_tiles)).  Since ABI v6 the slot is position p_t(w) * M / n_workgroups of the step's keyed bijection p_t of the
+ * workgroup indices (the Feistel network DEVICE mode applies to rows): every workgroup evaluates its own entry, there is
+ * no schedule kernel or buffer behind a default call, and this export returns exactly those integers.
+ * NOTE (small populations): a workgroup's 16 * row_tiles rows are CONSECUTIVE run indices, so when pop < 16 * row_tiles -- or
+ * where a workgroup straddles the end of one particle's run -- several particles of the same candidate sit in one workgroup
+ * and share a member at every step; the reference's per-row assignment (gaussian_mlp.py:267-275) gives them independent,
+ * balanced members.  DEVICE mode (the default of the Python layer) has the reference's semantics at every size.
+ * normals DEVICE f32 [H, B, out_dim] = the eps the kernel draws for (step, row, dim) with the same (seed, stream_id).     */
 int hipets_fast_schedule(hipets_engine* e, int32_t horizon, int32_t n_workgroups, uint64_t seed, uint64_t stream_id,
                          int32_t* schedule, void* stream);
 int hipets_fast_normals(hipets_engine* e, int32_t horizon, int32_t batch, uint64_t seed, uint64_t stream_id,

@@ -64,14 +64,6 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n1 = r * __builtin_amdgcn_sinf(u);
 }
 
-// 64-bit mix (splitmix64 finaliser) for sort keys of the balanced member schedule
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Counter-based random permutation of [0, n): the device-side stand-in for the reference's per-step
 // torch.randperm(B) (mbrl/models/gaussian_mlp.py:203-205).  A mixed-radix alternating Feistel network on
@@ -135,6 +127,32 @@ __host__ __device__ inline uint32_t perm_apply(uint32_t x, uint32_t n, uint32_t 
         x = L * b + R;
     } while (x >= n);
     return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST mode: member slot of workgroup `wg` (of `nwg`) at `step` -- the block-balanced stand-in for the reference's per-row
+// balanced shuffle (mbrl/models/gaussian_mlp.py:203-205, 267-275) at workgroup granularity.  The step's keyed bijection of
+// [0, nwg) (the same Feistel network DEVICE mode applies to rows) is cut into M equal runs (position p -> slot, with a per-step
+// rotation): every slot gets floor / ceil(nwg / M) workgroups, exactly, and every workgroup meets every slot with probability 1 / M.  O(1) per workgroup: every workgroup evaluates its own entry
+// in its prologue (until round 6 a separate kernel ranked nwg sort keys, O(nwg^2): 80 us in front of a ModelEnv.step of
+// 100 000 rows).  (a, b) = perm_radices(nwg).  step = 0xFFFFFFFF: the one draw of a TS-infinity (fixed_model) rollout.
+// BasicEnsemble (iid != 0): every workgroup draws independently and uniformly (randint, basic_ensemble.py:122-129).
+// hipets_fast_schedule exports exactly these integers; oracle/device_draws.member_schedule restates them.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t fast_member_key(uint64_t seed, uint64_t stream, uint32_t step) {
+    return perm_mix64(seed ^ perm_mix64(stream * 0x9E3779B97F4A7C15ull + 0x46415354ull /* "FAST" */) ^ ((uint64_t)step << 32));
+}
+__host__ __device__ inline int fast_member(uint32_t wg, uint32_t nwg, uint32_t a, uint32_t b, int M, int iid, uint64_t seed, uint64_t stream,
+                                           uint32_t step) {
+    const uint64_t key = fast_member_key(seed, stream, step);
+    if (iid) return (int)(((perm_mix64(key + (uint64_t)wg) >> 32) * (uint64_t)M) >> 32);
+    const uint32_t p = perm_apply(wg, nwg, a, b, perm_round_keys(key));
+    // positions p * M + r on a circle of nwg * M points cut into M arcs of nwg: floor / ceil(nwg / M) workgroups per slot whatever the
+    // step's rotation r in [0, nwg * M) -- which makes every slot equally likely for every workgroup (it decides WHICH slots get the
+    // extra workgroup and, for nwg < M, which slots are used at all: without it three workgroups of a five-member model would only
+    // ever run members 0, 1 and 3)
+    const uint32_t r = perm_scale((uint32_t)(perm_mix64(key ^ 0x4F46465345545F52ull /* "OFFSET_R" */) >> 32), nwg * (uint32_t)M);
+    return (int)((((uint64_t)p * (uint64_t)M + r) / nwg) % (uint64_t)M);
 }
 
 }  // namespace hipets

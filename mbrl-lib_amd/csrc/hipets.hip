@@ -91,7 +91,7 @@ struct hipets_engine {
     DevBuf w3pack;  // bf16x3 precision mode: weight pieces
     DevBuf wpack, bpack, layer_meta, norm_mean, norm_std, min_lv, max_lv, no_delta, members;
     // rollout workspace
-    DevBuf s0, state, totals, term, schedule, plan_schedule;
+    DevBuf s0, state, totals, term;
     // DEVICE mode, persistent form: row exchange table, per-step permutation keys, timeout flag (host-mapped)
     DevBuf exchange, step_keys, plan_keys;
     // host -> device staging of the caller's observations: a small ring of pinned buffers owned by the engine, so the async
@@ -192,8 +192,6 @@ size_t lds_for(const hipets_engine* e, int R, int horizon, bool wide = false) {
 // instead of 4 per row tile at hid 200).  Step-synchronous launches (DEVICE / EXACT: hand-over or one launch per step) pay the busiest one.
 // Calibrated on MI355X (profiles/r4_stock_workloads.json, r4_learned_reward_workloads.json, r4_device_r_sweep.json: every R forced, 12
 // workloads, both modes -- the rule picks the fastest R in 23 of the 24 cases and loses 0.3 % in the other).
-// member_schedule_kernel: blocks per (step, rollout) -- one per 256 workgroups whose slot they rank (rollout_helpers.hpp)
-inline unsigned schedule_slices(int nwg) { return (unsigned)std::max(1, std::min(64, (nwg + 255) / 256)); }
 
 // FAST-mode geometry: the B = pop x P rows are one run (rollout.hpp, prologue) of ceil(B / 16) row tiles, R per workgroup
 inline long long fast_tiles(long long pop, int P) { return (pop * P + kTile - 1) / kTile; }
@@ -239,7 +237,6 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
     return best;
 }
 
-// Plan-level prologue shared by the fused plans: stage the observation(s) once and, for member-sampling propagation,
 // copy `bytes` of caller HOST memory to `dst` on `st`: memcpy into the next pinned slot of the engine's ring, async copy from
 // there.  A slot is reused only after the copy that last read it has executed (its event; normally long complete).
 int stage_h2d(hipets_engine* e, void* dst, const void* src, size_t bytes, hipStream_t st) {
@@ -285,15 +282,13 @@ struct StreamScope {
     if (enter_stream((e), (st))) return 1; \
     StreamScope stream_scope_ { (e), (st) }
 
-// generate the member schedules of `iters` consecutive FAST rollouts (stream ids first_stream, +1, ...) of `pop` candidates
-// in ONE launch.  *sched = schedule of rollout 0 (rollout i: + i * H * nwg) or nullptr (expectation propagation).
-int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, int H, int iters, uint64_t seed, uint64_t first_stream,
-                  hipStream_t st, const int** sched, size_t* sched_stride) {
+// Plan-level prologue shared by the fused plans: stage the observation(s) once (the same for every iteration) and, for DEVICE-mode
+// plans, generate the per-step permutation keys of ALL `iters` rollouts (stream ids first_stream, +1, ...) in one launch.  (FAST-mode
+// rollouts need nothing up front since round 6: every workgroup draws its own member schedule in its prologue, common.hpp fast_member.)
+int plan_prologue(hipets_engine* e, const float* s0, int n_env, int H, int iters, uint64_t seed, uint64_t first_stream, hipStream_t st) {
     const ModelDev& md = e->md;
     if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
     if (stage_h2d(e, e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, st)) return 1;
-    *sched = nullptr;
-    *sched_stride = 0;
     if (md.propagation == HIPETS_PROP_RANDOM_MODEL && iters >= 1 && e->plan_mode == HIPETS_MODE_DEVICE && e->persistent_ok) {
         // the per-step permutation keys of every rollout of the plan in one launch (rollout_impl finds them by seed / stream id)
         if (e->plan_keys.ensure((size_t)iters * H * sizeof(PermKeys))) return 1;
@@ -301,20 +296,7 @@ int plan_prologue(hipets_engine* e, const float* s0, int n_env, int pop, int P, 
                            (unsigned long long)first_stream);
         HCHECK(hipGetLastError());
         e->plan_keys_seed = seed; e->plan_keys_first = first_stream; e->plan_keys_count = iters; e->plan_keys_H = H;
-        return 0;
     }
-    if (md.propagation == HIPETS_PROP_EXPECTATION || iters < 1 || e->plan_mode != HIPETS_MODE_FAST) return 0;
-    const long long tiles = fast_tiles(pop, P);
-    const int R = choose_R(e, tiles, 1, 0, H, wide_model(md) && n_env == 1, true);  // the fused plans' rollouts are lean calls unless batched
-    const int nwg = (int)((tiles + R - 1) / R);
-    if (nwg > 8000) return 0;  // the rollout reports the error
-    if (e->plan_schedule.ensure((size_t)iters * H * nwg * 4)) return 1;
-    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, iters, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->plan_schedule.as<int>(), nwg, md.M,
-                       md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)seed,
-                       (unsigned long long)first_stream);
-    HCHECK(hipGetLastError());
-    *sched = e->plan_schedule.as<int>();
-    *sched_stride = (size_t)H * nwg;
     return 0;
 }
 
@@ -469,7 +451,7 @@ void hipets_destroy(hipets_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
     for (DevBuf* b : {&e->w3pack, &e->wpack, &e->bpack, &e->layer_meta, &e->norm_mean, &e->norm_std, &e->min_lv, &e->max_lv, &e->no_delta, &e->members,
-                      &e->s0, &e->state, &e->totals, &e->term, &e->schedule, &e->plan_schedule, &e->exchange, &e->step_keys, &e->plan_keys, &e->mu, &e->disp, &e->population, &e->values,
+                      &e->s0, &e->state, &e->totals, &e->term, &e->exchange, &e->step_keys, &e->plan_keys, &e->mu, &e->disp, &e->population, &e->values,
                       &e->best_value, &e->best_solution, &e->past_action, &e->kept, &e->elite_idx, &e->keep_idx, &e->planet_w, &e->planet_b, &e->planet_member, &e->planet_ops, &e->shard_values, &e->gathered, &e->census})
         b->release();
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -668,9 +650,11 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     return 0;
 }
 
-int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizon, int32_t mode, int32_t* kernel_class, int32_t* row_tiles) {
+int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizon, int32_t mode, int32_t rows_per_group, int32_t* kernel_class,
+                        int32_t* row_tiles) {
     if (!e || !e->has_model) return fail("engine has no model");
     if (pop < 1 || P < 1 || horizon < 1) return fail("bad pop/horizon/particles");
+    if (rows_per_group < 0 || rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
     if (mode != HIPETS_MODE_FAST && mode != HIPETS_MODE_DEVICE) return fail("hipets_kernel_class: mode must be HIPETS_MODE_FAST or HIPETS_MODE_DEVICE");
     const ModelDev& md = e->md;
     RolloutArgs probe{};  // what a default call's arguments look like to the launcher: in-kernel draws, nothing injected or traced
@@ -691,8 +675,8 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
         tiles = fast_tiles(pop, P);
         slices = 1;
     }
-    const bool wide = wide_model(md) && call_lean;
-    const int R = choose_R(e, tiles, slices, 0, horizon, wide, mode == HIPETS_MODE_FAST);
+    const bool wide = wide_model(md) && call_lean && rows_per_group <= 2;
+    const int R = choose_R(e, tiles, slices, rows_per_group, horizon, wide, mode == HIPETS_MODE_FAST);
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("the model does not fit LDS");
     int cls = HIPETS_KERNEL_GENERIC;
     if (md.precision == HIPETS_PREC_BF16X3) {
@@ -715,11 +699,10 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
 }  // extern "C"
 
 namespace {
-// hipets_rollout with two plan-level shortcuts: s0 == nullptr means the initial state(s) are already staged in e->s0
-// (the observation is the same for every iteration of a plan), `presched` is a member schedule [H, n_workgroups] the
-// plan generated up front for this rollout (one launch for all iterations instead of one per rollout).
+// hipets_rollout with a plan-level shortcut: s0 == nullptr means the initial state(s) are already staged in e->s0
+// (the observation is the same for every iteration of a plan).
 int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
-                 const hipets_rollout_opts* o, float* returns, void* stream, const int* presched);
+                 const hipets_rollout_opts* o, float* returns, void* stream);
 }
 
 extern "C" {
@@ -730,14 +713,14 @@ int hipets_rollout(hipets_engine* e, const float* actions, const float* s0, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     ENTER_STREAM(e, st);
-    return rollout_impl(e, actions, s0, pop, H, P, o, returns, stream, nullptr);
+    return rollout_impl(e, actions, s0, pop, H, P, o, returns, stream);
 }
 
 }  // extern "C"
 
 namespace {
 int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_t pop, int32_t H, int32_t P,
-                 const hipets_rollout_opts* o, float* returns, void* stream, const int* presched) {
+                 const hipets_rollout_opts* o, float* returns, void* stream) {
     if (!e || !e->has_model) return fail("engine has no model (call hipets_set_model)");
     if (!actions || !o) return fail("null argument");  // (returns == nullptr: internal callers that fold the particle mean)
     if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
@@ -756,8 +739,8 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
     if (o->rows_per_group < 0 || o->rows_per_group > kMaxR) return fail("rows_per_group outside [0, %d]", kMaxR);
 
     const int n_env = o->n_env > 1 ? o->n_env : 1;
-    if (n_env > 1 && (o->mode != HIPETS_MODE_FAST || pop % n_env != 0))
-        return fail("n_env %d needs FAST mode and a population (%d) divisible by it", n_env, pop);
+    if (n_env > 1 && ((o->mode != HIPETS_MODE_FAST && o->mode != HIPETS_MODE_DEVICE) || pop % n_env != 0))
+        return fail("n_env %d needs FAST or DEVICE mode and a population (%d) divisible by it", n_env, pop);
     if (e->s0.ensure((size_t)n_env * md.obs_dim * 4)) return 1;
     if (e->totals.ensure((size_t)B * 4)) return 1;
     if (s0 && stage_h2d(e, e->s0.p, s0, (size_t)n_env * md.obs_dim * 4, st)) return 1;
@@ -863,7 +846,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         if (!persistent) {  // the persistent form starts from s0 itself and writes every row's total at the end
             hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((B * md.obs_dim + 255) / 256)), dim3(256), 0, st,
                                e->state.as<float>(), e->totals.as<float>(), e->term.as<unsigned char>(), e->s0.as<float>(), (int)B,
-                               md.obs_dim);
+                               md.obs_dim, P, ra.pop_env);
             HCHECK(hipGetLastError());
         }
         if (persistent) {
@@ -928,20 +911,12 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
         const int nwg = groups;
         if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d); shard the population", nwg);
         ra.groups = groups;
-        if (md.propagation != HIPETS_PROP_EXPECTATION) {
-            if (o->member_schedule) {
-                ra.schedule = o->member_schedule;
-            } else if (presched) {
-                ra.schedule = presched;
-            } else {
-                if (e->schedule.ensure((size_t)H * nwg * 4)) return 1;
-                hipLaunchKernelGGL(member_schedule_kernel, dim3(H, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
-                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
-                                   (unsigned long long)o->stream_id);
-                HCHECK(hipGetLastError());
-                ra.schedule = e->schedule.as<int>();
-            }
-        }
+        if (o->member_schedule && o->member_schedule_len != 0 && (long long)o->member_schedule_len != (long long)H * nwg)
+            return fail("member_schedule holds %d entries, this call's geometry is horizon %d x %d workgroups (hipets_fast_geometry)",
+                        o->member_schedule_len, H, nwg);
+        // the caller's schedule, or (null) every workgroup draws its own entries in its prologue (common.hpp fast_member)
+        ra.schedule = md.propagation != HIPETS_PROP_EXPECTATION ? o->member_schedule : nullptr;
+        perm_radices((uint32_t)nwg, &ra.fm_a, &ra.fm_b);
         ra.t_begin = 0;
         ra.t_end = H;
         if (launch_rollout(e, R, nwg, lds, ra, st)) return 1;
@@ -999,7 +974,7 @@ int check_shards(const hipets_engine* e, const int rows, const int P) {
 // candidate's return on every rank.  The caller has sized e->values / shard_values / gathered.  Returns non-zero only when the
 // collective itself failed (RCCL error: the plan is over for everybody); local failures go to *le and the collective still runs.
 int sharded_evaluate(hipets_engine* e, const float* population, const int rows, const int H, const int P, const hipets_rollout_opts* ro,
-                     const int* presched, void* stream, LocalErr* le) {
+                     void* stream, LocalErr* le) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int world = e->comm_world, rank = e->comm_rank;
     int lo, hi;
@@ -1007,7 +982,7 @@ int sharded_evaluate(hipets_engine* e, const float* population, const int rows, 
     const int width = (rows + world - 1) / world;
     const size_t nd = (size_t)H * e->md.act_dim;
     float* shard_out = world == 1 ? e->values.as<float>() : e->shard_values.as<float>();
-    if (le->ok()) le->note(rollout_impl(e, population + (size_t)lo * nd, nullptr, hi - lo, H, P, ro, shard_out, stream, presched));
+    if (le->ok()) le->note(rollout_impl(e, population + (size_t)lo * nd, nullptr, hi - lo, H, P, ro, shard_out, stream));
     if (world > 1) {  // every rank, every iteration, whatever happened locally
         NCHECK(g_rccl.AllGather(e->shard_values.p, e->gathered.p, (size_t)width, 7 /* ncclFloat32 */, e->comm, st));
         if (le->ok()) {
@@ -1081,12 +1056,17 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         ra.groups = (int)((tiles + R - 1) / R);
         ra.rows_per_domain = rpd;
-        if (device) {  // a ModelEnv.step of a TS-infinity rollout keeps its member map: the caller keeps (seed, stream_id) fixed
+        if (device) {
             ra.use_philox = o->no_sample ? 0 : 1;
             if (!expectation) {
                 ra.perm_n = (unsigned)B;
                 perm_radices((uint32_t)B, &ra.perm_a, &ra.perm_b);
-                ra.perm_keys = perm_round_keys(perm_key(o->seed, o->stream_id, md.propagation == HIPETS_PROP_FIXED_MODEL ? 0xFFFFFFFFu : 0u));
+                // random_model: the permutation of (seed, stream_id), step 0.  fixed_model (a ModelEnv.step of a TS-infinity rollout keeps
+                // its member map while the eps change): the TS-infinity permutation of (seed, perm_stream_id) -- the stream of the reset --
+                // next to eps drawn from (seed, stream_id), the stream of the step
+                const bool fixed = md.propagation == HIPETS_PROP_FIXED_MODEL;
+                const uint64_t pstream = (fixed && o->perm_stream_id) ? o->perm_stream_id : o->stream_id;
+                ra.perm_keys = perm_round_keys(perm_key(o->seed, pstream, fixed ? 0xFFFFFFFFu : 0u));
             }
         } else {
             ra.perm = expectation ? nullptr : reinterpret_cast<const long long*>(o->perms);
@@ -1096,29 +1076,29 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         }
         if (launch_rollout(e, R, domains * ra.groups, lds, ra, st)) return 1;
     } else if (o->mode == HIPETS_MODE_FAST) {
+        // One step of B independent rows: workgroup w owns rows [w * 16 R, (w + 1) * 16 R) and runs the member the FAST rule gives it
+        // (the caller's schedule, else common.hpp fast_member).  For ONE step the per-step launch form -- rows and state in HBM around
+        // the launch -- IS the FAST form, and every shape-specialised instance has it: the launch below is a DEVICE-form launch with
+        // the identity permutation (one domain of B rows) and RolloutArgs::fast_members.  (Until round 6 this was a FAST-path launch
+        // with per-row initial states, which only the generic / hidden-static instances have, behind a member-schedule kernel that
+        // ranked all workgroups' sort keys: a 100 000-row call took 0.44 ms where DEVICE mode took 0.34.)
         const long long tiles = (B + kTile - 1) / kTile;
         const int R = choose_R(e, tiles, 1, o->rows_per_group, 1, false, true);
         const size_t lds = lds_for(e, R, 1);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int nwg = (int)((tiles + R - 1) / R);
         if (nwg > 8000) return fail("FAST mode supports at most 8000 workgroups per launch (got %d)", nwg);
+        if (o->member_schedule && o->member_schedule_len != 0 && o->member_schedule_len != nwg)
+            return fail("member_schedule holds %d entries, this call's geometry is %d workgroups (hipets_fast_geometry with rows_per_group -1)",
+                        o->member_schedule_len, nwg);
+        ra.mode = HIPETS_MODE_DEVICE;  // the kernel's per-step launch form (see above); nothing else reads the mode
         ra.groups = nwg;
+        ra.rows_per_domain = B;
         ra.eps = o->fast_eps;
         ra.use_philox = (o->fast_eps || o->no_sample) ? 0 : 1;
-        ra.init_states = next_obs;
-        ra.write_back = 1;
-        if (md.propagation != HIPETS_PROP_EXPECTATION) {
-            if (o->member_schedule) {
-                ra.schedule = o->member_schedule;
-            } else {
-                if (e->schedule.ensure((size_t)nwg * 4)) return 1;
-                hipLaunchKernelGGL(member_schedule_kernel, dim3(1, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, st, e->schedule.as<int>(), nwg, md.M,
-                                   md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, md.iid_members, (unsigned long long)o->seed,
-                                   (unsigned long long)o->stream_id);
-                HCHECK(hipGetLastError());
-                ra.schedule = e->schedule.as<int>();
-            }
-        }
+        ra.fast_members = 1;
+        ra.schedule = md.propagation != HIPETS_PROP_EXPECTATION ? o->member_schedule : nullptr;
+        perm_radices((uint32_t)nwg, &ra.fm_a, &ra.fm_b);
         if (launch_rollout(e, R, nwg, lds, ra, st)) return 1;
     } else {
         return fail("unknown rollout mode %d", o->mode);
@@ -1131,7 +1111,9 @@ int hipets_fast_schedule(hipets_engine* e, int32_t H, int32_t nwg, uint64_t seed
     if (!e || !e->has_model) return fail("engine has no model");
     if (!schedule || H < 1 || nwg < 1) return fail("bad argument");
     HCHECK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(member_schedule_kernel, dim3(H, 1, schedule_slices(nwg)), dim3(256), (size_t)nwg * 8, reinterpret_cast<hipStream_t>(stream), schedule, nwg,
+    uint32_t fa, fb;
+    perm_radices((uint32_t)nwg, &fa, &fb);
+    hipLaunchKernelGGL(member_schedule_kernel, dim3((unsigned)((nwg + 255) / 256), H), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), schedule, nwg, fa, fb,
                        e->md.M, e->md.propagation == HIPETS_PROP_FIXED_MODEL ? 1 : 0, e->md.iid_members, (unsigned long long)seed,
                        (unsigned long long)stream_id);
     HCHECK(hipGetLastError());
@@ -1330,7 +1312,6 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     if (!x0 || !lower || !upper || !s0 || !out) return fail("null argument");
     if (p->act_dim != e->md.act_dim) return fail("act_dim %d != model act_dim %d", p->act_dim, e->md.act_dim);
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
-    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     ENTER_STREAM(e, st);
@@ -1349,11 +1330,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
     ro.n_env = n_env;
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    const int* sched = nullptr;
-    size_t sched_stride = 0;
-    if (plan_prologue(e, s0, n_env, (int)npop, P, c.H, p->num_iterations, seed, plan_id * (uint64_t)p->num_iterations, st, &sched,
-                      &sched_stride))
-        return 1;
+    if (plan_prologue(e, s0, n_env, c.H, p->num_iterations, seed, plan_id * (uint64_t)p->num_iterations, st)) return 1;
     for (int i = 0; i < p->num_iterations; ++i) {
         const uint64_t sid = plan_id * (uint64_t)p->num_iterations + (uint64_t)i;
         const long long n = (long long)npop * c.D;
@@ -1363,9 +1340,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
         HCHECK(hipGetLastError());
         ro.stream_id = sid;
         // the particle mean of the returns (model_env.py:190-191) happens inside the refit kernel: one launch less per iteration
-        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, nullptr, stream,
-                         sched ? sched + (size_t)i * sched_stride : nullptr))
-            return 1;
+        if (rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, c.H, P, &ro, nullptr, stream)) return 1;
         int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * n_env * c.K : nullptr;
         CemDev cr = c;
         cr.totals = e->totals.as<float>();
@@ -1412,7 +1387,6 @@ int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t 
     if (H < 1 || num_iterations < 0) return fail("bad horizon/num_iterations");
     if (A != e->md.act_dim) return fail("act_dim %d != model act_dim %d", A, e->md.act_dim);
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
-    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     if (sharded && check_shards(e, pop, P)) return 1;  // identical on every rank, before any collective
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
@@ -1429,18 +1403,14 @@ int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t 
     ro.mode = e->plan_mode;
     ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_mppi)
     ro.n_env = n_env;
-    const int* sched = nullptr;
-    size_t sched_stride = 0;
-    int lo = 0, hi = pop;
-    if (sharded) shard_bounds(pop, world, rank, &lo, &hi);
+
     auto prologue = [&]() -> int {
         if (sharded) HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
         HCHECK(hipMemcpyAsync(e->mu.p, mean, n_env * nd * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(mppi_shift_kernel, dim3((unsigned)((n_env * nd + 255) / 256)), dim3(256), 0, st, n_env, H, A, e->mu.as<float>(), mean,
                            e->past_action.as<float>());
         HCHECK(hipGetLastError());
-        return plan_prologue(e, s0, n_env, sharded ? hi - lo : (int)npop, P, H, num_iterations, ro.seed, plan_id * (uint64_t)num_iterations, st, &sched,
-                             &sched_stride);
+        return plan_prologue(e, s0, n_env, H, num_iterations, ro.seed, plan_id * (uint64_t)num_iterations, st);
     };
     le.note(prologue());
     if (!sharded && !le.ok()) return le.report();
@@ -1462,11 +1432,10 @@ int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t 
         };
         if (le.ok()) le.note(sample());
         ro.stream_id = sid;
-        const int* ps = sched ? sched + (size_t)k * sched_stride : nullptr;
         if (sharded) {
-            if (sharded_evaluate(e, e->population.as<float>(), pop, H, P, &ro, ps, stream, &le)) return 1;
+            if (sharded_evaluate(e, e->population.as<float>(), pop, H, P, &ro, stream, &le)) return 1;
         } else if (le.ok()) {
-            le.note(rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, H, P, &ro, e->values.as<float>(), stream, ps));
+            le.note(rollout_impl(e, e->population.as<float>(), nullptr, (int32_t)npop, H, P, &ro, e->values.as<float>(), stream));
         }
         if (le.ok()) le.note(update());
         if (!sharded && !le.ok()) break;
@@ -1510,7 +1479,6 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
     if (K < 1 || keep < 0 || keep > K) return fail("elite_num %d / keep_elite_size %d invalid", K, keep);
     if (p->population_size < 1 || iters < 0 || !(p->population_decay_factor > 0.0)) return fail("bad iCEM parameters");
     if (n_env < 1 || n_env > 4096) return fail("n_env %d outside [1, 4096]", n_env);
-    if (n_env > 1 && e->plan_mode != HIPETS_MODE_FAST) return fail("batched planning (n_env > 1) runs FAST-mode rollouts: hipets_set_plan_mode(FAST)");
     // population sizes (:419-431) and the rows every iteration evaluates are known up front: size the workspace for the largest, and
     // (sharded) refuse on EVERY rank, before the first collective, what one rank's shard of some iteration could not take
     std::vector<int> sizes(iters), rows_of(iters);
@@ -1624,9 +1592,9 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
         if (le.ok()) le.note(sample());
         ro.stream_id = sid + 3;
         if (sharded) {
-            if (sharded_evaluate(e, popbuf, rows, H, P, &ro, nullptr, stream, &le)) return 1;
+            if (sharded_evaluate(e, popbuf, rows, H, P, &ro, stream, &le)) return 1;
         } else if (le.ok()) {
-            le.note(rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream, nullptr));  // s0 staged above
+            le.note(rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream));  // s0 staged above
         }
         if (le.ok()) le.note(refit());
         if (!sharded && !le.ok()) break;
@@ -1856,9 +1824,7 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     HCHECK(hipSetDevice(e->device));
     ENTER_STREAM(e, st);
     const CemDev c = make_cem(p, 1);
-    int lo, hi;
-    shard_bounds(c.pop, world, rank, &lo, &hi);
-    const int local = hi - lo, width = (c.pop + world - 1) / world;
+    const int width = (c.pop + world - 1) / world;
     const size_t nd = (size_t)c.D;
     if (e->mu.ensure(nd * 4) || e->disp.ensure(nd * 4) || e->best_solution.ensure(nd * 4) || e->best_value.ensure(16) ||
         e->population.ensure((size_t)c.pop * nd * 4) || e->values.ensure((size_t)c.pop * 4) || e->shard_values.ensure((size_t)width * 4) ||
@@ -1870,15 +1836,13 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
     ro.seed = seed + (uint64_t)rank * 0x9E3779B97F4A7C15ull;  // ranks draw independent rollout randomness (rank 0: as hipets_plan_cem)
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    const int* sched = nullptr;
-    size_t sched_stride = 0;
     auto prologue = [&]() -> int {
         hipLaunchKernelGGL(cem_init_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, c, x0, lower, upper, e->mu.as<float>(),
                            e->disp.as<float>(), e->best_value.as<float>());
         HCHECK(hipGetLastError());
         HCHECK(hipMemsetAsync(e->best_solution.p, 0, nd * 4, st));
         HCHECK(hipMemsetAsync(e->shard_values.p, 0, (size_t)width * 4, st));  // padding slot of the shorter shards
-        return plan_prologue(e, s0, 1, local, P, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st, &sched, &sched_stride);
+        return plan_prologue(e, s0, 1, c.H, p->num_iterations, ro.seed, plan_id * (uint64_t)p->num_iterations, st);
     };
     le.note(prologue());
     for (int i = 0; i < p->num_iterations; ++i) {
@@ -1901,7 +1865,7 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
         };
         if (le.ok()) le.note(sample());
         ro.stream_id = sid;
-        if (sharded_evaluate(e, e->population.as<float>(), c.pop, c.H, P, &ro, sched ? sched + (size_t)i * sched_stride : nullptr, stream, &le)) return 1;
+        if (sharded_evaluate(e, e->population.as<float>(), c.pop, c.H, P, &ro, stream, &le)) return 1;
         if (le.ok()) le.note(refit());
     }
     if (!le.ok()) return le.report();

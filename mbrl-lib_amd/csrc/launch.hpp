@@ -22,8 +22,10 @@ hipError_t launch_rollout_r4(int grid, unsigned lds, int lds_max, const ModelDev
 
 // Hidden widths with a KSpec::HID_STATIC instance (hidden layers shape-specialised, everything else generic): X(hidden column tiles).
 // 13 tiles = hidden widths 193..208: the reference's default of 200 (conf/dynamics_model/gaussian_mlp_ensemble.yaml:8), which every
-// configuration it ships uses; 8 and 16 tiles = the power-of-two widths people change hid_size to (113..128, 241..256).
-#define HIPETS_HID_STATIC_SHAPES(X) X(13) X(8) X(16)
+// configuration it ships uses.  (Rounds 4-5 also instantiated 8 and 16 tiles -- hid 113..128, 241..256: + 2-10 % over the generic
+// instance, profiles/r4_hidden_widths.json -- for widths no shipped configuration or BASELINE config has; round 6 dropped those eight
+// instances from the build: other widths run the generic instance, same bits.)
+#define HIPETS_HID_STATIC_SHAPES(X) X(13)
 
 // may this model / call run the hidden-static instance for `hc` hidden column tiles?  (SiLU, fp32 arithmetic, the LDS row stride the
 // instance was compiled for -- i.e. no layer wider than the hidden ones; RolloutArgs::generic_only == 1 forbids it, 2 allows it)
@@ -66,7 +68,9 @@ inline bool hid_static_call(const ModelDev& md, const RolloutArgs& ra, const int
 #define HIPETS_LEAN_FAST_SHAPES_R4(X)
 
 // bf16x3 precision instances per R: X(hidden column tiles, output column tiles, reward fn, termination fn); no obs preprocessing
-#define HIPETS_B3_SHAPES_R1(X) X(13, 1, HIPETS_REW_CARTPOLE, HIPETS_TERM_CARTPOLE) X(13, 3, HIPETS_REW_HALFCHEETAH, HIPETS_TERM_NONE)
+// (round 6: the R = 1 instances -- cfg1, and a rank's shard of a strong-scaled cfg2 plan, in an arithmetic mode that is reported
+// separately and parked -- are gone from the build too: four instances; the mode runs R = 3 instances or raises)
+#define HIPETS_B3_SHAPES_R1(X)
 // (round 5: the R = 2 instances are gone -- two workgroups per CU cap a wave at 256 registers, the three-piece fragments did not fit and
 // the two instances spilt 6 / 41 VGPRs to scratch, the only rollout kernels that did; the row-tile rule chooses among R = 1 and 3 for
 // this arithmetic mode, hipets.hip choose_R)

@@ -103,7 +103,12 @@ struct RolloutArgs {
     const float* eps;      // [H,B,out] or null
     int use_philox;        // FAST without eps override
     unsigned long long seed, stream_id;
-    const int* schedule;   // FAST: [H, nWG] member slot per (step, workgroup)
+    const int* schedule;   // FAST: [H, nWG] member slot per (step, workgroup), injected by the caller; null = every workgroup draws its own
+                           //   entries in its prologue (common.hpp fast_member, radices fm_a x fm_b = perm_radices(gridDim.x))
+    unsigned fm_a, fm_b;
+    int fast_members;      // the NON-fast kernel path (rows by identity / permutation, state in HBM around the launch) with the workgroup's
+                           //   member chosen as in FAST mode (`schedule`, or the in-kernel draw for step t_begin): hipets_step in FAST mode --
+                           //   for one step the per-step launch form IS the FAST form, and it exists in every shape-specialised instance
     float* trace_next_obs;
     float* trace_rewards;
     long long* phase_cycles;  // optional [kWaves][16 phases] cycle counters of workgroup 0 (profiling aid)
@@ -1299,7 +1304,9 @@ struct KSpec {
 #ifndef HIPETS_KSPLIT
 #define HIPETS_KSPLIT 1
 #endif
-    static constexpr bool KSPLIT = HIPETS_KSPLIT && FUSE && !WIDE && HIDC_ % kWaves == 1 && HIDC_ / kWaves >= 1 && HIDC_ / kWaves <= 3 && HIDC_ <= 16;
+    // (13 column tiles only: the consumer side, wave_gemm KSI inside KSO, rebuilds the last k chunk from slot kKsSlots - 1 of the last wave,
+    // which is where a 13-chunk range -- 3 + 3 + 3 + 4 chunks -- ends; a 5- or 9-tile shape would end in another slot and read unwritten LDS)
+    static constexpr bool KSPLIT = HIPETS_KSPLIT && FUSE && !WIDE && kWaves == 4 && HIDC_ == 13;
     // termination functions that test EVERY state dim (inverted_pendulum: isfinite(next_obs).all(), termination_fns.py:47-55) are fused for
     // models with obs_dim <= 4 only -- then dims 0..3 ARE every dim (launch.hpp fused_term_ok checks the model)
     static_assert(!FUSE || ((REW_ == HIPETS_REW_HALFCHEETAH || REW_ == HIPETS_REW_CARTPOLE || REW_ == HIPETS_REW_CARTPOLE_PETS || REW_ == HIPETS_REW_LEARNED) &&
@@ -1638,6 +1645,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #endif
     constexpr bool kPre = HIPETS_CROSS_LAYER_PREFETCH && kLean && PreOk<S::HIDC>::value && PreOk<S::OUTC>::value;
     constexpr bool kFuse = S::FUSE && !kPre;  // the output layer's accumulators feed the step's tail directly (KSpec::FUSE)
+    // the k-split ops of one-tile workgroups (mlp_layer: S::KSPLIT && R == 1) exist in the fused step flow only -- the generic flow
+    // passes no partial-sum buffer (a build with HIPETS_CROSS_LAYER_PREFETCH=1 turns kFuse off: it must not keep KSPLIT on)
+    static_assert(!(S::KSPLIT && R == 1) || kFuse, "k-split one-tile ops need the fused step flow (sm.part)");
     // facts that are template arguments in a lean instance and model / call fields in the generic one
     const int normalizer = S::NORM >= 0 ? S::NORM : md.normalizer;
     const int obs_process = S::OBSP >= 0 ? S::OBSP : md.obs_process;
@@ -1741,8 +1751,17 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             const int p = g / ra.pop, c = g - p * ra.pop;
             sm.rowid[s] = g < ra.B ? c * ra.P + p : -1;
         }
-        if (!expectation)
-            for (int t = tid; t < ra.H; t += kThreads) sm.sched[t] = ra.schedule[(size_t)t * gridDim.x + wg];
+        if (!expectation) {
+            // this workgroup's member slot of every step: the caller's schedule, or drawn here (one keyed bijection of the workgroup
+            // indices per step, thread t evaluates step t's: common.hpp fast_member)
+            if (ra.schedule) {
+                for (int t = tid; t < ra.H; t += kThreads) sm.sched[t] = ra.schedule[(size_t)t * gridDim.x + wg];
+            } else {
+                const bool fixed = md.propagation == HIPETS_PROP_FIXED_MODEL;
+                for (int t = tid; t < ra.H; t += kThreads)
+                    sm.sched[t] = fast_member((unsigned)wg, gridDim.x, ra.fm_a, ra.fm_b, md.M, md.iid_members, ra.seed, ra.stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t);
+            }
+        }
     } else {
         domain = wg / ra.groups;
         const int j0 = (wg % ra.groups) * ROWS;
@@ -1761,6 +1780,14 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             sm.rowid[s] = rid;
         }
     }
+    // the ensemble member this workgroup runs: its row domain's (reference semantics: slot j -> member j / (B / M)) -- or, for
+    // RolloutArgs::fast_members launches (one step of B independent rows, hipets_step in FAST mode), the FAST rule's
+    int member_dom = domain;
+    if (!fast && ra.fast_members && !expectation)
+        member_dom = __builtin_amdgcn_readfirstlane(
+            ra.schedule ? ra.schedule[(size_t)ra.t_begin * gridDim.x + wg]
+                        : fast_member((unsigned)wg, gridDim.x, ra.fm_a, ra.fm_b, md.M, md.iid_members, ra.seed, ra.stream_id,
+                                      md.propagation == HIPETS_PROP_FIXED_MODEL ? 0xFFFFFFFFu : (unsigned)ra.t_begin));
     const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
     const bool poll_every = ra.poll_ticks < 1000;  // bounds below 10 us (tests of the time-out path): look at the clock on every spin, not every 64th
     // hand-over table row = NVP pairs of 8-byte granules: the state dims (padded to an even count), then {running total, flag}.
@@ -1854,7 +1881,10 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         else if (!kLean && ra.pop_env > 0) v[q] = rid >= 0 ? ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d] : 0.f;
                         else v[q] = ra.s0[d];
                     } else if (rid >= 0) {
-                        v[q] = persist ? ra.s0[d] : ra.state[(size_t)rid * md.obs_dim + d];  // persistent form starts from the tiled s0 itself
+                        // persistent form: starts from the tiled s0 itself (batched planning: the s0 of the row's environment)
+                        if (!persist) v[q] = ra.state[(size_t)rid * md.obs_dim + d];
+                        else if (!kLean && ra.pop_env > 0) v[q] = ra.s0[(size_t)((rid / ra.P) / ra.pop_env) * md.obs_dim + d];
+                        else v[q] = ra.s0[d];
                     }
                 }
             }
@@ -2135,7 +2165,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     NextOp cur_op;  // ... and that op's descriptor
     cur_op.valid = false;
     if constexpr (kPre) {
-        const int m0 = fast ? __builtin_amdgcn_readfirstlane(sm.sched[ra.t_begin]) : domain;
+        const int m0 = fast ? __builtin_amdgcn_readfirstlane(sm.sched[ra.t_begin]) : member_dom;
         cur_op = describe_layer<R, S>(md, sm.lmeta, 0, m0, wave);
         prefetch_issue(cur_op, lane, pre);
     }
@@ -2266,7 +2296,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         const unsigned long long handover_tag = (unsigned long long)(ra.tag_base + (unsigned)t + 1u) << 32;  // tags never repeat across launches
         if constexpr (kFuse) {
             // ---- KSpec::FUSE: hidden layers as usual; the OUTPUT layer's accumulators go straight into the step's tail ----------
-            const int member = fast ? __builtin_amdgcn_readfirstlane(sm.sched[t]) : domain;  // wave-uniform
+            const int member = fast ? __builtin_amdgcn_readfirstlane(sm.sched[t]) : member_dom;  // wave-uniform
             float* cur = step_in;
             float* nxt = step_in == sm.buf0 ? sm.buf1 : sm.buf0;
             const int L = md.n_layers;
@@ -2491,7 +2521,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             for (int mi = 0; mi < n_run; ++mi) {
                 if (expectation) member = mi;
                 else if (fast) member = __builtin_amdgcn_readfirstlane(sm.sched[t]);  // wave-uniform: weight pointers stay in SGPRs
-                else member = domain;
+                else member = member_dom;
                 if (mi > 0) {  // expectation: layer 1 overwrote buf0, rebuild the same input for the next member
                     build_input(t, sm.buf0);
                     __syncthreads();
@@ -2506,7 +2536,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         nop.valid = false;
                         if (l + 1 < md.n_layers) nop = describe_layer<R, S>(md, sm.lmeta, l + 1, member, wave);
                         else if (t + 1 < ra.t_end)  // the next step's first op (its member: the schedule's next entry / the same domain)
-                            nop = describe_layer<R, S>(md, sm.lmeta, 0, fast ? __builtin_amdgcn_readfirstlane(sm.sched[t + 1]) : domain, wave);
+                            nop = describe_layer<R, S>(md, sm.lmeta, 0, fast ? __builtin_amdgcn_readfirstlane(sm.sched[t + 1]) : member_dom, wave);
                         mlp_layer_pre<R, S>(md, l + 1 == md.n_layers, cur_op, cur, nxt, wave, lane, prof, pre, nop);
                         cur_op = nop;
                         lds_barrier();
@@ -2686,6 +2716,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         if (persist && has_next) {
             // ---- collect the rows of the next turn: 8-byte {value bits, step tag} granules, self-validating ----
             domain = v_next / ra.groups;
+            member_dom = domain;
             compute_act_base();
             float av2[kPrefetch];
             fetch_actions_issue(t_next, av2);  // in flight while the rows arrive
@@ -2696,7 +2727,9 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             if (t_next == ra.t_begin) {  // a later turn of the FIRST step: the rows start from s0 (nothing was handed over yet)
                 for (int i = tid; i < ROWS * md.obs_dim; i += kThreads) {
                     const int s_ = i / md.obs_dim;
-                    sm.state[i] = sm.rowid[s_] >= 0 ? ra.s0[i - s_ * md.obs_dim] : 0.f;
+                    const int rid_ = sm.rowid[s_];
+                    const size_t env_off = (!kLean && ra.pop_env > 0 && rid_ >= 0) ? (size_t)((rid_ / ra.P) / ra.pop_env) * md.obs_dim : 0;
+                    sm.state[i] = rid_ >= 0 ? ra.s0[env_off + (i - s_ * md.obs_dim)] : 0.f;
                 }
                 for (int s_ = tid; s_ < ROWS; s_ += kThreads) {
                     sm.tot[s_] = 0.f;

@@ -7,10 +7,14 @@ namespace hipets {
 
 // ---- small helper kernels ---------------------------------------------------------------------------
 
-// model_env.py:170-176: tile s0, zero the accumulators (EXACT mode state lives in HBM between steps)
-__global__ void init_state_kernel(float* state, float* totals, unsigned char* term, const float* s0, int B, int obs_dim) {
+// model_env.py:170-176: tile s0, zero the accumulators (EXACT mode state lives in HBM between steps).  pop_env > 0 (batched planning):
+// row i belongs to candidate i / P, which plans for environment (i / P) / pop_env and starts from that environment's s0
+__global__ void init_state_kernel(float* state, float* totals, unsigned char* term, const float* s0, int B, int obs_dim, int P, int pop_env) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B * obs_dim) state[i] = s0[i % obs_dim];
+    if (i < B * obs_dim) {
+        const int row = i / obs_dim, d = i - row * obs_dim;
+        state[i] = s0[(pop_env > 0 ? (size_t)((row / P) / pop_env) * obs_dim : 0) + d];
+    }
     if (i < B) { totals[i] = 0.f; term[i] = 0; }
 }
 
@@ -23,40 +27,14 @@ __global__ void particle_mean_kernel(const float* totals, float* returns, int po
     returns[c] = s / (float)P;
 }
 
-// FAST-mode member schedule: per step a balanced random assignment of workgroups to member slots
-// (every slot gets floor/ceil(nWG/M) workgroups -- the reference's "each model gets exactly the same
-// number of samples", gaussian_mlp.py:267-275, at 16*R-row granularity).  fixed_model: one draw
-// for all steps (TS-infinity).  One block per step.
-// BasicEnsemble (iid != 0): every workgroup draws its slot independently and uniformly (randint,
-// basic_ensemble.py:122-129), no balancing.
-__global__ void member_schedule_kernel(int* sched, int nwg, int M, int fixed, int iid, unsigned long long seed,
+// Export of the FAST-mode member schedule (hipets_fast_schedule): sched[t][w] = the member slot workgroup w of nwg draws for step t
+// in its own prologue (common.hpp fast_member: one keyed bijection of the workgroup indices per step, cut into M equal runs -- the
+// reference's "each model gets exactly the same number of samples", gaussian_mlp.py:267-275, at 16 R-row granularity; fixed_model:
+// one draw for all steps; BasicEnsemble, iid != 0: independent uniform draws, basic_ensemble.py:122-129).  (a, b) = perm_radices(nwg).
+__global__ void member_schedule_kernel(int* sched, int nwg, unsigned a, unsigned b, int M, int fixed, int iid, unsigned long long seed,
                                        unsigned long long stream_id) {
-    extern __shared__ unsigned long long keys[];  // [nwg] sort keys of this step
-    const int t = blockIdx.x;
-    // blockIdx.y: consecutive rollouts of one plan (stream ids stream_id, stream_id + 1, ...), schedules back to back
-    stream_id += blockIdx.y;
-    sched += (size_t)blockIdx.y * gridDim.x * nwg;
-    const unsigned long long tk = fixed ? 0xFFFFFFFFull : (unsigned long long)t;
-    const unsigned long long base = mix64(seed ^ mix64(stream_id * 0x9E3779B97F4A7C15ull + tk));
-    for (int i = threadIdx.x; i < nwg; i += blockDim.x) keys[i] = mix64(base + (unsigned long long)i);
-    __syncthreads();
-    // blockIdx.z: slices of the workgroups whose slot is written here (every block computes ALL keys, then ranks its own slice: the
-    // rank count is O(nwg^2) -- ModelEnv.step on 100 000 rows is 6 250 workgroups, 1.1 ms in one block, round 5)
-    const int me0 = blockIdx.z * blockDim.x + threadIdx.x, me_step = blockDim.x * gridDim.z;
-    if (iid) {
-        for (int me = me0; me < nwg; me += me_step)
-            sched[(size_t)t * nwg + me] = (int)(((keys[me] >> 32) * (unsigned long long)M) >> 32);
-        return;
-    }
-    for (int me = me0; me < nwg; me += me_step) {
-        const unsigned long long kme = keys[me];
-        int rank = 0;
-        for (int i = 0; i < nwg; ++i) {
-            const unsigned long long ki = keys[i];
-            rank += (ki < kme) || (ki == kme && i < me);
-        }
-        sched[(size_t)t * nwg + me] = (int)(((long long)rank * M) / nwg);
-    }
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (w < nwg) sched[(size_t)t * nwg + w] = fast_member((unsigned)w, (unsigned)nwg, a, b, M, iid, seed, stream_id, fixed ? 0xFFFFFFFFu : (unsigned)t);
 }
 
 // export of the FAST-mode normals (hipets_fast_normals): out[t][rid][d]

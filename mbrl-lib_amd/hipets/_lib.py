@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HIPETS_LIB selects another build of the SAME library (kernel-variant experiments under profiles/); there is no fallback
 LIB_PATH = os.environ.get("HIPETS_LIB") or os.path.join(_HERE, "libhipets.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 8
 
 ACT = {"relu": 0, "silu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4}
@@ -55,6 +55,8 @@ class RolloutOpts(C.Structure):
         ("rows_per_member", C.c_int32),
         ("n_env", C.c_int32),
         ("generic_kernel", C.c_int32),
+        ("member_schedule_len", C.c_int32),
+        ("perm_stream_id", C.c_uint64),
     ]
 
 
@@ -106,7 +108,7 @@ SYMBOLS = {
     "hipets_rollout": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RolloutOpts), _P, _P]),
     "hipets_step": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RolloutOpts), _P, _P, _P, _P]),
     "hipets_fast_geometry": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "hipets_kernel_class": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hipets_kernel_class": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hipets_fast_schedule": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_fast_normals": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),
     "hipets_device_perms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P, _P]),

@@ -69,7 +69,7 @@ class Engine:
         self.planet_spec = None
         self.comm_world, self.comm_rank = 1, 0
         self.comm_group = None  # torch.distributed group of the communicator's ranks (hipets.dist.init_engine_comm)
-        self.plan_mode = "fast"
+        self.plan_mode = "fast"  # (the library's initial value; every fused plan sets its objective's mode: planning._prepare_fused)
         self._trace = None
         self._keep = []  # device tensors that must outlive async set_model work
 
@@ -159,8 +159,8 @@ class Engine:
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float32).reshape(-1))
         if s0.shape[0] != self.spec.obs_dim * max(1, n_env):
             raise ValueError(f"initial_state has {s0.shape[0]} values, expected n_env x obs_dim = {max(1, n_env)} x {self.spec.obs_dim}")
-        if n_env > 1 and (mode != "fast" or pop % n_env):
-            raise ValueError("batched rollouts (n_env > 1) need mode='fast' and a population divisible by n_env")
+        if n_env > 1 and (mode not in ("fast", "device") or pop % n_env):
+            raise ValueError("batched rollouts (n_env > 1) need mode='fast' or 'device' and a population divisible by n_env")
         B = pop * num_particles
         o = RolloutOpts()
         o.n_env = int(n_env)
@@ -191,7 +191,7 @@ class Engine:
             if member_schedule is not None:
                 nwg, _ = self.fast_geometry(pop, num_particles, H, rows_per_group)
                 _check_dev(member_schedule, torch.int32, dev, "member_schedule", (H, nwg))
-                o.member_schedule = _ptr(member_schedule)
+                o.member_schedule, o.member_schedule_len = _ptr(member_schedule), int(member_schedule.numel())
         o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
         if trace_next_obs is not None:
             _check_dev(trace_next_obs, torch.float32, dev, "trace_next_obs", (H, B, self.spec.obs_dim))
@@ -215,10 +215,12 @@ class Engine:
     def step(self, obs: torch.Tensor, actions: torch.Tensor, *, mode: str = "fast", sample: bool = True,
              perm: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, seed: int = 0, stream_id: int = 0,
              member_schedule: Optional[torch.Tensor] = None, rows_per_group: int = 0,
-             members: Optional[torch.Tensor] = None):
+             members: Optional[torch.Tensor] = None, perm_stream_id: int = 0):
         """One model transition for B independent rows (ModelEnv.step, mbrl/models/model_env.py:87-140).
         Returns (next_obs [B,obs], rewards [B,1], dones [B,1] bool) on the device.  ``members`` int64 [B]: EXACT-mode
-        member of every row for BasicEnsemble models (GaussianMLP models take ``perm``)."""
+        member of every row for BasicEnsemble models (GaussianMLP models take ``perm``).  ``perm_stream_id`` (DEVICE mode,
+        fixed_model propagation): the stream whose TS-infinity permutation the step uses -- the rollout's reset -- while
+        ``stream_id`` keys this step's eps; 0 = ``stream_id``."""
         if self.spec is None:
             raise HipetsError("Engine.set_model() has not been called")
         dev = self.device
@@ -232,6 +234,7 @@ class Engine:
         o.seed, o.stream_id = int(seed) & (2**64 - 1), int(stream_id) & (2**64 - 1)
         o.rows_per_group = int(rows_per_group)
         o.no_sample = int(not sample)
+        o.perm_stream_id = int(perm_stream_id) & (2**64 - 1)
         if mode == "device":
             if perm is not None or eps is not None or members is not None:
                 raise ValueError("mode='device' draws its permutation and eps in-kernel")
@@ -255,7 +258,7 @@ class Engine:
                 o.fast_eps = _ptr(eps)
             if member_schedule is not None:
                 _check_dev(member_schedule, torch.int32, dev, "member_schedule")
-                o.member_schedule = _ptr(member_schedule)
+                o.member_schedule, o.member_schedule_len = _ptr(member_schedule), int(member_schedule.numel())
         next_obs = torch.empty_like(obs)
         rewards = torch.empty(B, dtype=torch.float32, device=dev)
         dones = torch.empty(B, dtype=torch.uint8, device=dev)
@@ -270,11 +273,13 @@ class Engine:
                                                   C.byref(r)))
         return nwg.value, r.value
 
-    def kernel_class(self, pop: int, num_particles: int, horizon: int, mode: str = "device"):
+    def kernel_class(self, pop: int, num_particles: int, horizon: int, mode: str = "device", rows_per_group: int = 0):
         """(class name, row tiles per workgroup) of the rollout-kernel instance a default rollout / fused plan of this size runs on
-        the engine's model: "generic", "hidden_static", "fused" or "wide" (include/hipets.h, hipets_kernel_class).  Diagnostic."""
+        the engine's model: "generic", "hidden_static", "fused" or "wide" (include/hipets.h, hipets_kernel_class); ``rows_per_group``
+        > 0: the answer for a call that forces that row-tile count.  Diagnostic."""
         cls, r = C.c_int32(), C.c_int32()
-        _lib.check(self._lib.hipets_kernel_class(self._h, pop, num_particles, horizon, _lib.MODES[mode], C.byref(cls), C.byref(r)))
+        _lib.check(self._lib.hipets_kernel_class(self._h, pop, num_particles, horizon, _lib.MODES[mode], int(rows_per_group), C.byref(cls),
+                                                 C.byref(r)))
         return _lib.KERNEL_CLASSES[cls.value], r.value
 
     def fast_schedule(self, horizon: int, n_workgroups: int, seed: int = 0, stream_id: int = 0) -> torch.Tensor:

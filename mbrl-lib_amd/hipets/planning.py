@@ -50,13 +50,15 @@ class HipTrajectoryEvalFn:
     Built from a live ``mbrl.models.ModelEnv`` (weights are re-snapshotted whenever
     ``ModelTrainer.train`` changed them) or from a ``ModelSpec``.  Randomness modes:
 
-    * ``'device'``: the reference's propagation semantics -- ONE balanced random permutation of all
+    * ``'device'`` (THE DEFAULT since round 6): the reference's propagation semantics -- ONE balanced random permutation of all
       ``pop * particles`` rows per step (gaussian_mlp.py:203-205), iid eps per row and dim -- with both drawn
       in-kernel from ``(seed, call counter)`` (a keyed bijection + Philox).  ONE persistent launch for the horizon (rows
       change workgroups through an in-kernel hand-over table); one launch per step where that form does not apply
       (``Engine.set_persistent(False)``, batches beyond two workgroups per CU) -- same bits either way.
-    * ``'fast'``: one launch for the whole horizon; each workgroup (particle p of 16-48 consecutive candidates)
-      draws one member per step from a balanced schedule: same marginals, block-wise common random numbers.
+    * ``'fast'`` (opt-in; ~8 % faster at cfg2): one launch for the whole horizon; each workgroup (particle p of 16-48 consecutive
+      candidates) draws one member per step from a balanced schedule: same marginals, block-wise common random numbers --
+      NOT the reference's per-row shuffle (held to the statistical tests only; with fewer than 16-48 candidates several particles
+      of one candidate share a member at every step, include/hipets.h hipets_fast_schedule).
     * ``'exact'``: replays the reference's own draws from torch's RNGs in the reference's order (one
       ``randperm(B)`` per step from the global generator, one ``normal_`` per step from ``rng``): seed-identical
       to ``ModelEnv.evaluate_action_sequences`` (a parity aid: it synchronises with the host).
@@ -64,7 +66,7 @@ class HipTrajectoryEvalFn:
       member maps with torch's device generator).
     """
 
-    def __init__(self, model, num_particles: int, engine: Optional[Engine] = None, mode: str = "fast",
+    def __init__(self, model, num_particles: int, engine: Optional[Engine] = None, mode: str = "device",
                  seed: int = 0, device=None, rng: Optional[torch.Generator] = None):
         if mode not in ("fast", "device", "exact", "exact_device"):
             raise ValueError("mode must be 'fast', 'device', 'exact' or 'exact_device'")
@@ -212,8 +214,10 @@ class ModelEnv:
     ``reset`` / ``step`` (one transition for a batch of independent rows: what MBPO-style model rollouts and the
     visualisers call) and ``evaluate_action_sequences``.  Built from a ``ModelSpec`` or a live mbrl ``ModelEnv``."""
 
-    def __init__(self, model, engine: Optional[Engine] = None, mode: str = "fast", seed: int = 0, device=None,
+    def __init__(self, model, engine: Optional[Engine] = None, mode: str = "device", seed: int = 0, device=None,
                  generator: Optional[torch.Generator] = None):
+        """``mode`` as for :class:`HipTrajectoryEvalFn`: 'device' (default; the reference's per-row balanced member shuffle and iid
+        eps, drawn in-kernel), 'fast' (one member per workgroup of 16-48 consecutive rows), 'exact' (the reference's own torch draws)."""
         self._eval = HipTrajectoryEvalFn(model, 1, engine=engine, mode=mode, seed=seed, device=device, rng=generator)
         self.engine, self.device, self.mode, self.seed = self._eval.engine, self._eval.device, mode, int(seed)
         self._return_as_np = True
@@ -221,6 +225,14 @@ class ModelEnv:
         self._fixed_perm = None
         self._fixed_members = None
         self._fixed_schedule = None
+        self._reset_stream = 0
+
+    def _step_mode(self) -> str:
+        """Kernel mode of ``step`` for the in-kernel randomness modes: 'device' where the library has it (GaussianMLP ensembles; any
+        model under expectation propagation), else 'fast' (BasicEnsemble: iid member draws per workgroup)."""
+        if self.mode in ("device", "exact_device") and (self.spec.ensemble_kind != "basic_ensemble" or self.spec.propagation == "expectation"):
+            return "device"
+        return "fast"
 
     @property
     def spec(self) -> ModelSpec:
@@ -243,6 +255,11 @@ class ModelEnv:
                 return {"obs": obs, "propagation_indices": self._fixed_members}
             if self.mode == "exact":
                 self._fixed_perm = torch.randperm(B).to(self.device)
+            elif self._step_mode() == "device":
+                # the TS-infinity permutation of this rollout: keyed by the stream of the reset, evaluated in-kernel at every step
+                # (hipets_rollout_opts.perm_stream_id); exported here as the reference's ``propagation_indices``
+                self._reset_stream = self._steps + 1
+                self._fixed_perm = self.engine.device_perms(1, B, self.seed, self._reset_stream)
             else:
                 nwg, _ = self.engine.fast_geometry(B, 1, 1, -1)  # hipets_step runs the general kernel layout
                 self._fixed_schedule = self.engine.fast_schedule(1, nwg, self.seed, self._steps + 1).contiguous()
@@ -273,6 +290,10 @@ class ModelEnv:
             if sample and not self.spec.deterministic:
                 eps = torch.empty(B, self.spec.out_dim).normal_(0.0, 1.0, generator=self._eval._cpu_rng()).to(self.device)
             nobs, rew, done = self.engine.step(obs, actions, mode="exact", sample=sample, perm=perm, eps=eps, members=members)
+        elif self._step_mode() == "device":
+            fixed = self.spec.propagation == "fixed_model"
+            nobs, rew, done = self.engine.step(obs, actions, mode="device", sample=sample, seed=self.seed, stream_id=self._steps,
+                                               perm_stream_id=self._reset_stream if fixed else 0)
         else:
             nobs, rew, done = self.engine.step(obs, actions, mode="fast", sample=sample, seed=self.seed, stream_id=self._steps,
                                                member_schedule=self._fixed_schedule)
@@ -293,12 +314,17 @@ class UnfusedTrajectoryEvalFn:
     (SURVEY.md section 2.1 row 6 "documented unfused fallback"): the horizon loop of
     ``ModelEnv.evaluate_action_sequences`` (model_env.py:178-191) runs on the host, every model transition is ONE fused
     ``hipets_step`` launch (input build, ensemble MLP, sampling, delta), and the user's callables run as torch ops on
-    the returned device tensors.  Same block-balanced TS1 / Philox randomness as the fused FAST path."""
+    the returned device tensors.  ``step_mode='device'`` (default): every step draws the reference's balanced per-row member
+    shuffle and iid eps in-kernel; ``'fast'``: one member per workgroup of 16-48 consecutive rows (also what BasicEnsemble
+    models run: the library's DEVICE mode has no iid-member variant)."""
 
     mode = "unfused"
 
     def __init__(self, model, num_particles: int, reward_fn=None, termination_fn=None, engine: Optional[Engine] = None,
-                 seed: int = 0, device=None):
+                 seed: int = 0, device=None, step_mode: str = "device"):
+        if step_mode not in ("device", "fast"):
+            raise ValueError("step_mode must be 'device' or 'fast'")
+        self.step_mode = step_mode
         self.num_particles, self.seed, self.calls = int(num_particles), int(seed), 0
         self._model_env, self._version = None, None
         if isinstance(model, ModelSpec):
@@ -346,13 +372,19 @@ class UnfusedTrajectoryEvalFn:
         total = torch.zeros(pop * P, 1, device=self.device)
         terminated = torch.zeros(pop * P, 1, dtype=torch.bool, device=self.device)
         schedule = None
-        if self.spec.propagation == "fixed_model":  # TS-infinity: one member map for the whole horizon (model.py:404-407)
+        device_mode = self.step_mode == "device" and (self.spec.ensemble_kind != "basic_ensemble" or self.spec.propagation == "expectation")
+        fixed = self.spec.propagation == "fixed_model"  # TS-infinity: one member map for the whole horizon (model.py:404-407)
+        if fixed and not device_mode:
             nwg, _ = self.engine.fast_geometry(pop * P, 1, 1, -1)  # hipets_step runs the general kernel layout
             schedule = self.engine.fast_schedule(1, nwg, self.seed, self.calls * 4096).contiguous()
         for t in range(H):
             act = torch.repeat_interleave(a_seq[:, t, :], P, dim=0).contiguous()  # model_env.py:179-182
-            nobs, rew, done = self.engine.step(obs, act, mode="fast", sample=True, seed=self.seed, stream_id=self.calls * 4096 + t,
-                                               member_schedule=schedule)
+            if device_mode:  # (stream ids of a call start at calls * 4096 + 1: 0 means "none" for perm_stream_id)
+                nobs, rew, done = self.engine.step(obs, act, mode="device", sample=True, seed=self.seed, stream_id=self.calls * 4096 + 1 + t,
+                                                   perm_stream_id=self.calls * 4096 + 1 if fixed else 0)
+            else:
+                nobs, rew, done = self.engine.step(obs, act, mode="fast", sample=True, seed=self.seed, stream_id=self.calls * 4096 + t,
+                                                   member_schedule=schedule)
             if self.reward_fn is not None:
                 rew = self.reward_fn(act, nobs)
             if self.termination_fn is not None:
@@ -372,11 +404,15 @@ class PlaNetTrajectoryEvalFn:
     model's saved posterior sample and belief (``update_posterior``, planet.py:600-640), read from the live model at every
     call, or set with :meth:`set_state` when built from a ``PlaNetSpec``.
 
-    ``mode='fast'``: in-kernel Philox draws; ``mode='exact'``: the reference's draws (one ``randn([B, latent])`` per step
-    from the generator) made on the host and injected."""
+    ``mode='device'`` (default; ``'fast'`` is the same thing here): iid standard normals per (row, step, latent dim) drawn
+    in-kernel from Philox counters -- a PlaNet model has no ensemble, so there is no member shuffle to approximate and the two
+    in-kernel modes of the PETS objective coincide with the reference's semantics; ``mode='exact'``: the reference's draws (one
+    ``randn([B, latent])`` per step from the generator) made on the host and injected."""
 
-    def __init__(self, model, num_particles: int = 1, engine: Optional[Engine] = None, mode: str = "fast", seed: int = 0,
+    def __init__(self, model, num_particles: int = 1, engine: Optional[Engine] = None, mode: str = "device", seed: int = 0,
                  device=None, rng: Optional[torch.Generator] = None):
+        if mode not in ("device", "fast", "exact"):
+            raise ValueError("mode must be 'device' (= 'fast': in-kernel draws) or 'exact'")
         self.num_particles, self.mode, self.seed, self.calls = int(num_particles), mode, int(seed), 0
         self._planet, self._version, self._state = None, None, None
         if isinstance(model, PlaNetSpec):
@@ -443,7 +479,7 @@ class PlaNetTrajectoryEvalFn:
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
         self.calls += 1
         latent0, belief0 = self._state
-        if self.mode == "fast":
+        if self.mode in ("fast", "device"):
             return self.engine.planet_rollout(a, latent0, belief0, self.num_particles, seed=self.seed, stream_id=self.calls)
         pop, H, _ = a.shape
         B = pop * self.num_particles
@@ -460,7 +496,9 @@ class PlaNetTrajectoryEvalFn:
 def make_eval_fn(model, num_particles: int, **kw):
     """``agent.set_trajectory_eval_fn(hipets.make_eval_fn(model_env, num_particles))`` on a stock or a
     hipets agent (seam 3 of SURVEY.md section 8b).  Returns the fully fused objective when reward / termination are
-    mbrl.env closed forms, the unfused one (fused model step + Python callables) when they are arbitrary callables."""
+    mbrl.env closed forms, the unfused one (fused model step + Python callables) when they are arbitrary callables.
+    Without a ``mode=`` argument the objective runs ``mode='device'``: the reference's TS1 semantics (one balanced permutation
+    of all rows per step, gaussian_mlp.py:201-211), every draw made in-kernel; ``mode='fast'`` is the opt-in block-balanced variant."""
     if isinstance(model, PlaNetSpec) or is_planet_model(getattr(model, "dynamics_model", model)):
         return PlaNetTrajectoryEvalFn(model, num_particles, **kw)
     try:
@@ -472,6 +510,8 @@ def make_eval_fn(model, num_particles: int, **kw):
         if spec.custom_reward_fn is None and spec.custom_termination_fn is None:
             raise
         kw2 = {k: v for k, v in kw.items() if k in ("engine", "seed", "device")}
+        if kw.get("mode") in ("fast", "device"):
+            kw2["step_mode"] = kw["mode"]
         return UnfusedTrajectoryEvalFn(model, num_particles, **kw2)
 
 
@@ -494,7 +534,7 @@ def _fused_target(obj_fun, planet_ok: bool = False):
         fn = obj_fun.eval_fn
         if isinstance(fn, HipTrajectoryEvalFn) and fn.kernel_mode is not None:
             return fn
-        if planet_ok and isinstance(fn, PlaNetTrajectoryEvalFn) and fn.mode == "fast":
+        if planet_ok and isinstance(fn, PlaNetTrajectoryEvalFn) and fn.mode in ("fast", "device"):
             return fn
     return None
 
@@ -570,7 +610,7 @@ class CEMOptimizer(Optimizer):
     """Cross-Entropy Method with device-side sampling and elite refit (trajectory_opt.py:43-188).
 
     Works with ANY ``obj_fun`` (generic path: one sample kernel + ``obj_fun`` + one refit kernel per
-    iteration, no host synchronisation of its own); when ``obj_fun`` is a hipets objective in fast mode
+    iteration, no host synchronisation of its own); when ``obj_fun`` is a hipets objective that draws in-kernel (device or fast mode)
     and no callback is given, the whole optimisation is one ``hipets_plan_cem`` call."""
 
     def __init__(self, num_iterations: int, elite_ratio: float, population_size: int,
@@ -1087,13 +1127,15 @@ class BatchedCEMAgent(Agent):
     """Batched planning: one CEM plan per environment for ``n_env`` environments (vectorised envs,
     MPC for many agents) in ONE set of launches.  Same algorithm per environment as ``TrajectoryOptimizerAgent`` +
     ``CEMOptimizer`` (warm start shifted by ``replan_freq`` per environment, trajectory_opt.py:563-567); a single cfg2
-    plan leaves 36 of 256 CUs idle, a batch fills the chip."""
+    plan leaves 36 of 256 CUs idle, a batch fills the chip.  The rollouts run the objective's randomness mode: 'device' (default:
+    one balanced permutation per step over the rows of ALL environments -- every row meets every member with probability 1 / M and
+    the members stay exactly balanced, as in a single reference plan) or 'fast'."""
 
     def __init__(self, eval_fn: HipTrajectoryEvalFn, n_env: int, action_lb: Sequence[float], action_ub: Sequence[float],
                  planning_horizon: int, num_iterations: int, elite_ratio: float, population_size: int, alpha: float,
                  return_mean_elites: bool = True, clipped_normal: bool = False, replan_freq: int = 1, seed: int = 0):
-        if eval_fn.mode != "fast":
-            raise ValueError("batched planning runs the FAST rollout path")
+        if eval_fn.kernel_mode is None:
+            raise ValueError("batched planning needs an objective with in-kernel randomness (mode='device' or 'fast')")
         self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
         self.n_env, self.horizon, self.replan_freq = int(n_env), int(planning_horizon), int(replan_freq)
         lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)
@@ -1117,8 +1159,8 @@ class BatchedCEMAgent(Agent):
         if self.engine.spec is not self.eval_fn.spec:
             self.engine.set_model(self.eval_fn.spec)
         self.eval_fn.check_batch(self._params.population_size)
-        if self.engine.plan_mode != "fast":
-            self.engine.set_plan_mode("fast")
+        if self.engine.plan_mode != self.eval_fn.kernel_mode:
+            self.engine.set_plan_mode(self.eval_fn.kernel_mode)
         self.calls += 1
         best = self.engine.plan_cem(self._params, self.previous_solution, self.lower, self.upper, obs_batch,
                                     self.eval_fn.num_particles, seed=self.seed ^ self.eval_fn.seed, plan_id=self.calls,
@@ -1141,8 +1183,8 @@ class BatchedMPPIAgent(Agent):
     def __init__(self, eval_fn: HipTrajectoryEvalFn, n_env: int, action_lb: Sequence[float], action_ub: Sequence[float],
                  planning_horizon: int, num_iterations: int, population_size: int, gamma: float, sigma: float, beta: float,
                  seed: int = 0):
-        if eval_fn.mode != "fast":
-            raise ValueError("batched planning runs the FAST rollout path")
+        if eval_fn.kernel_mode is None:
+            raise ValueError("batched planning needs an objective with in-kernel randomness (mode='device' or 'fast')")
         self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
         self.n_env, self.horizon = int(n_env), int(planning_horizon)
         lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)
@@ -1176,8 +1218,8 @@ class BatchedICEMAgent(Agent):
                  planning_horizon: int, num_iterations: int, elite_ratio: float, population_size: int, population_decay_factor: float,
                  colored_noise_exponent: float, keep_elite_frac: float, alpha: float, return_mean_elites: bool = True,
                  population_size_module: Optional[int] = None, replan_freq: int = 1, seed: int = 0):
-        if eval_fn.mode != "fast":
-            raise ValueError("batched planning runs the FAST rollout path")
+        if eval_fn.kernel_mode is None:
+            raise ValueError("batched planning needs an objective with in-kernel randomness (mode='device' or 'fast')")
         self.eval_fn, self.engine, self.device = eval_fn, eval_fn.engine, eval_fn.device
         self.n_env, self.horizon, self.replan_freq = int(n_env), int(planning_horizon), int(replan_freq)
         lb, ub = np.asarray(action_lb, np.float32), np.asarray(action_ub, np.float32)

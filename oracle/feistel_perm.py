@@ -45,10 +45,15 @@ def _hash32(v, k):
 
 def permutation(n: int, seed: int, stream: int, step: int) -> np.ndarray:
     """perm[j] for j in [0, n): the row slot j holds at `step` (step = 0xFFFFFFFF: the TS-infinity permutation)."""
+    with np.errstate(over="ignore"):
+        return permutation_from_key(n, perm_key(seed, stream, step))
+
+
+def permutation_from_key(n: int, key) -> np.ndarray:
+    """perm_apply(j, n, radices(n), perm_round_keys(key)) for j in [0, n) (also behind FAST mode's member schedule: device_draws)."""
     a, b = radices(n)
     with np.errstate(over="ignore"):
-        key = perm_key(seed, stream, step)
-        ks = [int(mix64(key + np.uint64(r)) >> np.uint64(16)) & 0xFFFFFFFF for r in range(ROUNDS)]
+        ks = [int(mix64(np.uint64(key) + np.uint64(r)) >> np.uint64(16)) & 0xFFFFFFFF for r in range(ROUNDS)]
     x = np.arange(n, dtype=np.uint64)
     out = np.empty(n, dtype=np.int64)
     todo = np.arange(n)

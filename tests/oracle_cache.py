@@ -61,16 +61,37 @@ class _Group:
             self.dirty = False
 
 
-def cached(group: str, inputs, compute, verify: bool = False):
+PIN_META, PIN_HEAD = ":meta", ":head"  # suffixes of an entry's pin records (see `cached`)
+
+
+def _pin(g, key, pin):
+    """Store, next to entry `key`, what a machine WITHOUT a GPU needs to re-derive a part of it (tests/test_oracle_memo_pinned.py):
+    `meta` -- a JSON-able dict naming the case, the randomness mode and the (seed, stream) counters of the engine's draws -- and
+    `head` -- the first few candidates of the population the engine recorded (the whole population would be megabytes per entry;
+    a candidate's return depends on its own rows only, so the head can be replayed on its own)."""
+    import json
+
+    g.used.update((key + PIN_META, key + PIN_HEAD))
+    if key + PIN_META in g.data and key + PIN_HEAD in g.data:
+        return
+    g.data[key + PIN_META] = np.frombuffer(json.dumps(pin["meta"], sort_keys=True).encode(), dtype=np.uint8).copy()
+    g.data[key + PIN_HEAD] = pin["head"].detach().cpu().contiguous().numpy().copy()
+    g.dirty = True
+
+
+def cached(group: str, inputs, compute, verify: bool = False, pin=None):
     """`compute()` (an oracle call) memoised under the digest of `inputs` (tensors, arrays, plain values) in file `group`.
     verify=True (one full-size case per randomness mode, round-4 advice): the oracle runs even on a hit -- so the exports its
     `compute` pulls from the engine (hipets_fast_normals, ...) stay exercised at full size -- and the stored entry must equal what
-    it returns NOW (bound: a tenth of the tests' T2); the fresh value is what the test then compares the device with."""
+    it returns NOW (bound: a tenth of the tests' T2); the fresh value is what the test then compares the device with.
+    pin={"meta": dict, "head": tensor}: see `_pin`."""
     g = _groups.get(group)
     if g is None:
         g = _groups[group] = _Group(group)
     key = _digest(inputs)
     g.used.add(key)
+    if pin is not None:
+        _pin(g, key, pin)
     if key in g.data and verify:
         stats["verified"] = stats.get("verified", 0) + 1
         fresh = compute()

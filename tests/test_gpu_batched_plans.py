@@ -1,6 +1,8 @@
 """Batched planning for MPPI and iCEM (hipets_plan_mppi_batched / hipets_plan_icem_batched): n_env
 environments per set of launches.  n_env = 1 is bit-identical to the single-environment fused plan; a batch is replayed
-PER ENVIRONMENT through the oracle with the engine's exported draws (teacher-forced per iteration for iCEM)."""
+PER ENVIRONMENT through the oracle with the engine's exported draws (teacher-forced per iteration for iCEM), in both in-kernel
+randomness modes: 'device' (the default of the Python layer: one balanced permutation per step over the rows of ALL environments) and
+'fast'."""
 import numpy as np
 import pytest
 import torch
@@ -16,19 +18,31 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def batched_replay(engine, om, s0, P, H, seed):
+def batched_members(engine, om, pop, P, H, seed, stream, mode):
+    """[H, pop * P] member slot of every row of a batched launch, from the engine's exported draws of (seed, stream)."""
+    B = pop * P
+    if mode == "device":  # slot j holds row perms[t][j] and runs member j // (B / M) (gaussian_mlp.py:164-166, 203-205), over ALL environments' rows
+        perms = engine.device_perms(H, B, seed, stream).cpu()
+        M = len(om.active_members)
+        members = torch.empty(H, B, dtype=torch.long)
+        for t in range(H):
+            members[t][perms[t]] = torch.arange(B) // (B // M)
+        return members
+    nwg, r = engine.fast_geometry(pop, P, H)
+    sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
+    wg = device_draws.fast_row_workgroup(torch.arange(B), P, r)
+    return torch.stack([sched[t][wg].long() for t in range(H)])
+
+
+def batched_replay(engine, om, s0, P, H, seed, mode):
     """values of ALL environments' candidates [n_env * rows] for (population_all, stream): every environment's slice goes through
-    the oracle with that slice of the launch's member schedule and eps."""
+    the oracle with that slice of the launch's row -> member map and eps."""
     def f(population_all, stream):
         n_env = s0.shape[0]
         pop = population_all.shape[0]
         rows_env = pop // n_env
-        nwg, r = engine.fast_geometry(pop, P, H)
-        sched = engine.fast_schedule(H, nwg, seed, stream).cpu()
         eps = engine.fast_normals(H, pop * P, seed, stream).cpu()
-        rows = torch.arange(pop * P)
-        wg = device_draws.fast_row_workgroup(rows, P, r)
-        members = torch.stack([sched[t][wg].long() for t in range(H)])
+        members = batched_members(engine, om, pop, P, H, seed, stream, mode)
         out = []
         for e_ in range(n_env):
             sl = slice(e_ * rows_env * P, (e_ + 1) * rows_env * P)
@@ -38,10 +52,11 @@ def batched_replay(engine, om, s0, P, H, seed):
     return f
 
 
-def test_batched_mppi_plans(engine):
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_batched_mppi_plans(engine, mode):
     obs, act, H, P, pop, n_env, iters = 17, 6, 9, 5, 120, 3, 3
     om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=6)
-    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=3)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=3, mode=mode)
     lb, ub = [-1.0] * act, [1.0] * act
     s0 = (np.random.default_rng(1).standard_normal((n_env, obs)) * 0.3).astype(np.float32)
     # n_env = 1 == the single-environment fused plan, bit for bit, over two consecutive (shifted) plans
@@ -61,7 +76,7 @@ def test_batched_mppi_plans(engine):
         torch.cuda.synchronize()
         engine.set_plan_trace(0)
         seed, plan_id = agent.seed ^ fn.seed, agent.calls
-        roll = batched_replay(engine, om, s0, P, H, seed)
+        roll = batched_replay(engine, om, s0, P, H, seed, mode)
         z = []
         for k in range(iters):
             buf = torch.empty(n_env * pop, H, act, device=DEV)
@@ -86,10 +101,11 @@ def test_batched_mppi_plans(engine):
     assert plans.shape == (n_env, H, act) and agent.act(s0).shape == (n_env, act)
 
 
-def test_batched_icem_plans(engine):
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_batched_icem_plans(engine, mode):
     obs, act, H, P, pop, n_env, iters, module = 17, 6, 8, 5, 150, 3, 4, 5
     om = po.make_synthetic_model(obs, act, ensemble_size=7, hid=48, seed=9, elite=[0, 1, 2, 3, 4])
-    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=3)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), P, engine=engine, seed=3, mode=mode)
     lb, ub = [-1.0] * act, [1.0] * act
     s0 = (np.random.default_rng(2).standard_normal((n_env, obs)) * 0.3).astype(np.float32)
     kw = dict(num_iterations=iters, elite_ratio=0.1, population_size=pop, population_decay_factor=1.3, colored_noise_exponent=2.0,
@@ -123,7 +139,7 @@ def test_batched_icem_plans(engine):
         torch.cuda.synchronize()
         engine.set_plan_trace(0)
         seed, plan_id = agent.seed ^ fn.seed, agent.calls
-        roll = batched_replay(engine, om, s0, P, H, seed)
+        roll = batched_replay(engine, om, s0, P, H, seed, mode)
         rows_i, noise_i, tail_i = [], [], None
         for i in range(iters):
             sid = (plan_id * iters + i) * 4

@@ -15,7 +15,8 @@ from test_gpu_rollout import SIZES, _random_case, assert_returns_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-B3_CASES = [SIZES[0], SIZES[1], SIZES[3], SIZES[4], (17, 6, 7, 5, 4, dict(ensemble_size=5, hid=200))]
+# (cfg1's shape -- one-tile workgroups only -- lost its bf16x3 instances in round 6's trim of the build: the mode runs R = 3 instances)
+B3_CASES = [SIZES[0], SIZES[3], SIZES[4], (17, 6, 7, 5, 4, dict(ensemble_size=5, hid=200))]
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])

@@ -336,8 +336,16 @@ def test_icem_and_mppi_with_engine_objective(engine):
     assert (r[:3] > r[3:].max() + 0.5).all(), r
 
 
-def test_batched_rollout_replayed_through_oracle_per_environment(engine):
-    """n_env environments in one FAST launch: candidates of environment g start from s0[g]; replayed per environment."""
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_batched_rollout_replayed_through_oracle_per_environment(engine, mode, persistent):
+    """n_env environments in one launch: candidates of environment g start from s0[g]; replayed per environment.  DEVICE mode (round 6):
+    one balanced permutation per step over the rows of ALL environments, in the persistent form (rows start from their environment's
+    s0 inside the kernel) and in per-step launches (init_state_kernel tiles the environments' s0)."""
+    from test_gpu_batched_plans import batched_members
+
+    if mode == "fast" and not persistent:
+        pytest.skip("FAST mode has one launch form")
     obs, act, H, P, pop_env, n_env = 17, 6, 5, 5, 30, 4
     om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=8)
     engine.set_model(to_spec(om, obs, act))
@@ -345,21 +353,22 @@ def test_batched_rollout_replayed_through_oracle_per_environment(engine):
     actions = torch.rand(n_env * pop_env, H, act, generator=g) * 2 - 1
     s0 = (torch.randn(n_env, obs, generator=g) * 0.3).numpy().astype(np.float32)
     seed, sid = 5, 9
-    out = engine.rollout(actions.to(DEV), s0, P, mode="fast", seed=seed, stream_id=sid, n_env=n_env).cpu()
+    engine.set_persistent(persistent)
+    try:
+        out = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=seed, stream_id=sid, n_env=n_env).cpu()
+    finally:
+        engine.set_persistent(True)
     pop = n_env * pop_env
-    nwg, r = engine.fast_geometry(pop, P, H)
-    sched = engine.fast_schedule(H, nwg, seed, sid).cpu()
     eps = engine.fast_normals(H, pop * P, seed, sid).cpu()
-    rows = torch.arange(pop * P)
-    wg = device_draws.fast_row_workgroup(rows, P, r)
-    members = torch.stack([sched[t][wg].long() for t in range(H)])
+    members = batched_members(engine, om, pop, P, H, seed, sid, mode)
     for e_ in range(n_env):
         sl = slice(e_ * pop_env * P, (e_ + 1) * pop_env * P)
         ref = po.rollout(om, actions[e_ * pop_env:(e_ + 1) * pop_env], s0[e_], P, members=members[:, sl], eps=eps[:, sl])
         assert torch.allclose(out[e_ * pop_env:(e_ + 1) * pop_env], ref, rtol=0, atol=1e-4)
 
 
-def test_batched_cem_planning(engine):
+@pytest.mark.parametrize("mode", ["device", "fast"])
+def test_batched_cem_planning(engine, mode):
     """hipets_plan_cem_batched: n_env = 1 is bit-identical to the single-environment plan; a batch gives every environment
     a good plan for ITS observation (scored by the oracle), and the warm start shifts per environment."""
     from hipets.planning import _BoundObjective
@@ -368,7 +377,7 @@ def test_batched_cem_planning(engine):
     om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=48, seed=6)
     om.max_logvar = torch.full_like(om.max_logvar, -8.0)
     spec = to_spec(om, obs, act)
-    fn = hipets.make_eval_fn(spec, P, engine=engine, seed=3)
+    fn = hipets.make_eval_fn(spec, P, engine=engine, seed=3, mode=mode)
     lb, ub = [-1.0] * act, [1.0] * act
     single = hipets.CEMOptimizer(4, 0.1, pop, [lb] * H, [ub] * H, 0.1, DEV, return_mean_elites=True, seed=7)
     s0 = (np.random.default_rng(1).standard_normal((n_env, obs)) * 0.3).astype(np.float32)

@@ -289,6 +289,92 @@ def test_step_exact_matches_oracle(engine, prop, sample):
     assert torch.equal(done.cpu(), rd) and 0 < int(rd.sum()) < B  # a mix of terminated / alive rows
 
 
+@pytest.mark.parametrize("prop", ["random_model", "fixed_model"])
+def test_model_env_class_default_mode_has_reference_semantics(engine, prop):
+    """hipets.ModelEnv() WITHOUT a mode argument (round 6: 'device'): reset / step draw the reference's per-row balanced member shuffle
+    (gaussian_mlp.py:201-211; TS-infinity: ONE shuffle at reset, model.py:404-407, kept for every step while the eps change) and iid eps
+    in-kernel.  Two consecutive steps replayed through the oracle with the exported permutation(s) and normals."""
+    import hipets
+
+    obs, act, B = 17, 6, 120
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=32, seed=3, propagation=prop)
+    env = hipets.ModelEnv(to_spec(om, obs, act), engine=engine, seed=11)
+    assert env.mode == "device"
+    g = torch.Generator().manual_seed(0)
+    obs0 = (torch.randn(B, obs, generator=g) * 0.2).numpy()
+    a1, a2 = torch.rand(B, act, generator=g) * 2 - 1, torch.rand(B, act, generator=g) * 2 - 1
+    state = env.reset(obs0, return_as_np=False)
+    n1, r1, d1, state = env.step(a1.to(DEV), state, sample=True)
+    n2, r2, d2, state = env.step(a2.to(DEV), state, sample=True)
+    if prop == "fixed_model":  # the reset's stream (1) keys the permutation of both steps; propagation_indices is that permutation
+        p1 = p2 = engine.device_perms(1, B, 11, 1).cpu()
+        assert torch.equal(state["propagation_indices"].cpu(), p1)
+    else:
+        p1, p2 = engine.device_perms(1, B, 11, 1).cpu()[0], engine.device_perms(1, B, 11, 2).cpu()[0]
+        assert not torch.equal(p1, p2)
+    e1, e2 = engine.fast_normals(1, B, 11, 1).cpu()[0], engine.fast_normals(1, B, 11, 2).cpu()[0]
+    x0 = torch.from_numpy(obs0.astype(np.float32))
+    rn1, rr1, _ = po.step(om, x0, a1, perm=p1, eps=e1, sample=True)
+    assert torch.allclose(n1.cpu(), rn1, rtol=1e-5, atol=2e-6) and torch.allclose(r1.cpu(), rr1, rtol=1e-5, atol=2e-6)
+    rn2, rr2, _ = po.step(om, n1.cpu(), a2, perm=p2, eps=e2, sample=True)
+    assert torch.allclose(n2.cpu(), rn2, rtol=1e-5, atol=2e-6) and torch.allclose(r2.cpu(), rr2, rtol=1e-5, atol=2e-6)
+    assert not torch.equal(e1, e2)
+    # the objective built without a mode argument is the same mode (and evaluate_action_sequences runs it)
+    fn = hipets.make_eval_fn(to_spec(om, obs, act), 5, engine=engine)
+    assert fn.mode == "device" and fn.kernel_mode == "device"
+    vals = env.evaluate_action_sequences(torch.zeros(10, 4, act, device=DEV), obs0[0], 5)
+    assert vals.shape == (10,) and torch.isfinite(vals).all()
+
+
+@pytest.mark.parametrize("M,fixed,iid", [(5, False, False), (5, True, False), (7, False, False), (4, False, True)])
+def test_fast_schedule_export_is_the_cpu_restatement(engine, M, fixed, iid):
+    """hipets_fast_schedule (what every FAST workgroup draws for itself in its prologue, common.hpp fast_member) == oracle/device_draws.
+    member_schedule, integer for integer, from one workgroup to thousands; balanced to within one workgroup per slot; and with fewer
+    workgroups than members every member is still drawn (the per-step rotation)."""
+    kind = "basic_ensemble" if iid else "gaussian_mlp"
+    om = po.make_synthetic_model(6, 2, ensemble_size=M, hid=16, seed=1, propagation="fixed_model" if fixed else "random_model", ensemble_kind=kind)
+    engine.set_model(to_spec(om, 6, 2))
+    for nwg, H in [(1, 40), (3, 40), (32, 15), (209, 30), (504, 7), (6250, 2)]:
+        got = engine.fast_schedule(H, nwg, 1234, 77).cpu().numpy()
+        want = device_draws.member_schedule(H, nwg, M, 1234, 77, fixed=fixed, iid=iid)
+        assert np.array_equal(got, want), (nwg, H)
+        if not iid:
+            for t in range(H):
+                c = np.bincount(got[t], minlength=M)
+                assert c.max() - c.min() <= 1
+        if fixed:
+            assert (got == got[0]).all()
+    if not fixed:
+        few = engine.fast_schedule(400, 3, 5, 6).cpu().numpy()
+        assert set(np.unique(few).tolist()) == set(range(M))
+
+
+def test_member_schedule_of_another_geometry_is_refused(engine):
+    """ABI v6: a caller-provided member schedule states its length; one sized for another geometry fails the call instead of being read
+    with the wrong stride (round-5 advice: the FAST geometry changed under ABI v5)."""
+    import ctypes as C
+
+    from hipets import _lib
+
+    obs, act, pop, P, H = 17, 6, 64, 5, 4
+    om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=32, seed=3)
+    engine.set_model(to_spec(om, obs, act))
+    actions = torch.zeros(pop, H, act, device=DEV)
+    nwg, r = engine.fast_geometry(pop, P, H)
+    good = engine.fast_schedule(H, nwg, 1, 2)
+    ref = engine.rollout(actions, np.zeros(obs, np.float32), P, mode="fast", seed=1, stream_id=2)
+    same = engine.rollout(actions, np.zeros(obs, np.float32), P, mode="fast", seed=1, stream_id=2, member_schedule=good)
+    assert torch.equal(ref, same)  # the injected schedule IS the in-kernel draw
+    o = _lib.RolloutOpts()
+    o.mode, o.seed, o.stream_id = _lib.MODES["fast"], 1, 2
+    o.member_schedule, o.member_schedule_len = good.data_ptr(), H * nwg + 1
+    out = torch.empty(pop, device=DEV)
+    s0 = np.zeros(obs, np.float32)
+    rc = engine._lib.hipets_rollout(engine._h, C.c_void_p(actions.data_ptr()), s0.ctypes.data_as(C.c_void_p), pop, H, P, C.byref(o),
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"member_schedule holds" in engine._lib.hipets_last_error()
+
+
 def test_model_env_class_reset_step_fast_mode_replayed(engine):
     """hipets.ModelEnv.reset/step in FAST mode, replayed through the oracle with the exported schedule and normals."""
     import hipets
@@ -411,13 +497,17 @@ def test_gaussian_mlp_with_explicit_member_maps(engine, prop):
     assert torch.allclose(nobs.cpu(), r_nobs, rtol=1e-5, atol=2e-6) and torch.allclose(rew.cpu(), r_rew, rtol=1e-5, atol=2e-6)
 
 
-def assert_same_arithmetic(a, b, row_tiles):
-    """Two instances of the rollout kernel on the same call.  Bit for bit -- except where one of them is a FUSED instance with ONE row
-    tile per workgroup: those deal the k range of the 13th hidden column tile to the four waves (rollout.hpp KsArgs, round 5), i.e.
-    sum hidden columns 192..207 in another order; they agree with every other instance to rounding, which is held to a tenth of the
-    tolerance the same returns get against the oracle (T2)."""
+def assert_same_arithmetic(a, b, kernel_class):
+    """Two instances of the rollout kernel on the same call.  Bit for bit -- except where one of them is a K-SPLIT instance: the
+    FUSED (not WIDE) instances with ONE row tile per workgroup deal the k range of the 13th hidden column tile to the four waves
+    (rollout.hpp KSpec::KSPLIT, round 5), i.e. sum hidden columns 192..207 in another order; they agree with every other instance to
+    rounding, which is held to a tenth of the tolerance the same returns get against the oracle (T2).  `kernel_class` =
+    Engine.kernel_class(...) of the shape-specialised side: (class name, row tiles).  Everything else -- WIDE, hidden-static and
+    generic instances at any row-tile count, fused ones at R >= 2 -- must be bit for bit (round-5 advice: a blanket tolerance for
+    every one-tile call would let a summation-order or hazard regression in those through)."""
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    if row_tiles != 1:
+    cls, row_tiles = kernel_class
+    if not (cls == "fused" and row_tiles == 1):
         assert torch.equal(a, b)
         return
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
@@ -438,7 +528,7 @@ def test_shape_specialised_kernels_equal_the_generic_kernel_bitwise(engine, case
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=True)
     c = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, generic_kernel=2)  # the hidden-static instance
     assert torch.equal(b, c)
-    assert_same_arithmetic(a, b, engine.kernel_class(pop, P, H, mode)[1])
+    assert_same_arithmetic(a, b, engine.kernel_class(pop, P, H, mode))
 
 
 # every model of the reference's default hidden width (200) that has no shape-specialised instance: the workloads the reference
@@ -485,10 +575,10 @@ def test_hidden_static_instances_equal_the_generic_kernel_bitwise(engine, case, 
     b = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=True)
     c = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group, generic_kernel=2)
     assert torch.equal(b, c)  # hidden-static == generic, for every row-tile count
-    assert_same_arithmetic(a, b, rows_per_group or engine.kernel_class(pop, P, H, mode)[1])  # ... and the call's own (maybe fused) instance
+    assert_same_arithmetic(a, b, engine.kernel_class(pop, P, H, mode, rows_per_group=rows_per_group))  # ... and the call's own (maybe fused) instance
 
 
-# the other hidden widths with hidden-static instances: 8 and 16 column tiles (hid 113..128, 241..256)
+# other hidden widths, incl. the 8 and 16 column tiles (hid 113..128, 241..256) that had hidden-static instances in rounds 4-5
 HIDW_CASES = [(17, 6, 500, 20, 4, dict(ensemble_size=5, hid=256)),
               (17, 6, 40, 6, 5, dict(ensemble_size=3, hid=128)),
               (11, 3, 60, 5, 6, dict(ensemble_size=5, hid=120, termination="hopper", normalizer="f32")),
@@ -500,16 +590,17 @@ HIDW_CASES = [(17, 6, 500, 20, 4, dict(ensemble_size=5, hid=256)),
 
 
 @pytest.mark.parametrize("mode", ["fast", "device"])
-@pytest.mark.parametrize("rows_per_group", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("rows_per_group", [0, 1, 4])
 @pytest.mark.parametrize("case", HIDW_CASES, ids=lambda c: f"obs{c[0]}_pop{c[2]}x{c[3]}_H{c[4]}_hid{c[5]['hid']}")
-def test_hidden_static_instances_of_other_widths_equal_the_generic_kernel_bitwise(engine, case, mode, rows_per_group):
-    """SiLU models with 8 or 16 hidden column tiles (hid 113..128, 241..256 -- the reference ships 200 everywhere, but hid_size is the
-    first thing people change) get hidden-static instances too: same bits as the fully generic kernel for every row-tile count
-    that fits the LDS."""
+def test_models_of_other_hidden_widths_run_the_generic_instance(engine, case, mode, rows_per_group):
+    """SiLU models whose hidden layers are not 13 column tiles wide (the reference ships 200 everywhere, but hid_size is the first thing
+    people change) run the fully generic instance since round 6 (the hidden-static instances for 8 and 16 tiles were trimmed from the
+    build): `generic_kernel=2` -- "hidden-static allowed" -- and the default call return what the forced generic instance returns, for
+    every row-tile count that fits the LDS."""
     obs, act, pop, P, H, mkw = case
     om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, **mkw)
     engine.set_model(to_spec(om, obs, act))
-    assert engine.kernel_class(pop, P, H, mode)[0] == "hidden_static"
+    assert engine.kernel_class(pop, P, H, mode)[0] == "generic"
     try:
         a = engine.rollout(actions.to(DEV), s0, P, mode=mode, seed=11, stream_id=3, rows_per_group=rows_per_group)
     except hipets.HipetsError as exc:
@@ -551,11 +642,11 @@ def test_shipped_workloads_run_the_instance_class_the_docs_say(engine, wl, mode)
     assert cls == (want[mode] if isinstance(want, dict) else want) and 1 <= r <= 4
     a = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r)
     b = engine.rollout(actions.to(DEV), s0, 20, mode=mode, seed=5, stream_id=9, rows_per_group=r, generic_kernel=True)
-    assert_same_arithmetic(a, b, r)
+    assert_same_arithmetic(a, b, (cls, r))
 
 
 def test_kernel_class_of_other_models(engine):
-    for hid, want in ((64, "generic"), (128, "hidden_static"), (256, "hidden_static"), (512, "generic")):
+    for hid, want in ((64, "generic"), (128, "generic"), (256, "generic"), (512, "generic")):
         om, *_ = _random_case(17, 6, 8, 5, 2, ensemble_size=5, hid=hid)
         engine.set_model(to_spec(om, 17, 6))
         assert engine.kernel_class(500, 20, 30, "device")[0] == want

@@ -338,5 +338,6 @@ def test_committed_oracle_memo_is_loadable_and_small():
     for f in files:
         total += os.path.getsize(os.path.join(d, f))
         with np.load(os.path.join(d, f)) as z:
-            assert len(z.files) > 0 and all(len(k) == 32 for k in z.files)  # blake2b-128 hex digests
+            # blake2b-128 hex digests, plus the pin records of the plans memo (oracle_cache._pin: "<digest>:meta" / "<digest>:head")
+            assert len(z.files) > 0 and all(len(k.split(":")[0]) == 32 and k.split(":")[1:] in ([], ["meta"], ["head"]) for k in z.files)
     assert total < 4 << 20

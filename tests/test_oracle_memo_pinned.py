@@ -1,4 +1,4 @@
-"""The oracle memo (tests/golden/oracle_cache/rollout_sizes.npz) re-derived WITHOUT a GPU.
+"""The oracle memos (tests/golden/oracle_cache/rollout_sizes.npz, plans_full_size.npz) re-derived WITHOUT a GPU.
 
 The full-size GPU parity tests (tests/test_gpu_rollout.py, test_gpu_device_mode.py) compare the HIP rollout with the oracle's
 answer for the same seeded inputs, and since round 4 they read that answer from a memo keyed by the exact input bytes
@@ -17,7 +17,17 @@ numpy normals agree with those to ~1e-6 relative, so the recomputed returns agre
 is the tests' own T2 (|err| <= 1e-4 max(1, |v|)).  Workloads whose reward / termination is a threshold function of the state
 (cartpole: 0 / 1 per step) can flip one row's step on such an eps difference -- a return then moves by 1 / P; at most 0.5 % of a
 population's candidates may exceed T2 there, and never by more than 2 / P per step flipped (asserted).
+
+Plans memo (round 6): the replays of the fused plans (tests/test_gpu_plans_full_size.py) feed the oracle the populations the
+ENGINE recorded -- megabytes per entry, not functions of a seed.  Every entry therefore carries a pin record (oracle_cache._pin):
+the (seed, stream) counters of the engine's draws, the randomness mode, the FAST geometry's row-tile count, and the population's first
+candidates.  A candidate's return depends on its own rows only (their members, their eps), so the head is replayed here on its own:
+members from the restated permutations (DEVICE) / member schedule + row dealing (FAST), eps from the restated Philox normals, and the
+result must equal the head of the stored values to T2.  A change of oracle/device_draws.fast_row_workgroup, of the schedule or of
+the permutation restatement makes THIS test fail, on a machine without a GPU.
 """
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -124,3 +134,73 @@ def test_fast_row_dealing_restatement_is_the_headers_statement():
         assert np.array_equal(device_draws.fast_row_workgroup(torch.arange(B), P, r).numpy(), owner)
         assert device_draws.fast_workgroups(B, r) == owner.max() + 1 == -(-(-(-B // 16)) // r)
     assert device_draws.fast_workgroups(805 * 20, 2) == 504  # (per particle it was 26 x 20 = 520: a third round on 256 CUs)
+
+
+# ---- plans memo ------------------------------------------------------------------------------------------------------------
+
+def _plans_group():
+    g = oc._groups.get("plans_full_size") or oc._Group("plans_full_size")
+    assert g.data, "tests/golden/oracle_cache/plans_full_size.npz is missing or empty"
+    return g
+
+
+def _plan_pins():
+    g = _plans_group()
+    return sorted(k[: -len(oc.PIN_META)] for k in g.data if k.endswith(oc.PIN_META))
+
+
+def test_every_plans_memo_entry_carries_a_pin_record():
+    g = _plans_group()
+    values = [k for k in g.data if not k.endswith(oc.PIN_META) and not k.endswith(oc.PIN_HEAD)]
+    pins = set(_plan_pins())
+    assert values and set(values) == pins, f"{len(set(values) - pins)} entries without a pin record, {len(pins - set(values))} pins without an entry"
+
+
+def _head_members(meta, om, head_rows, B):
+    """[H, len(head_rows)] member slot of the head's rows at every step, from the CPU restatements of the engine's draws."""
+    H, seed, stream, P = meta["H"], meta["seed"], meta["stream"], meta["P"]
+    M = len(om.active_members)
+    fixed = om.propagation == "fixed_model"
+    if meta["mode"] == "device":  # slot j holds row perm[j] and runs member j // (B / M) (gaussian_mlp.py:164-166, 203-205)
+        out = np.empty((H, len(head_rows)), dtype=np.int64)
+        for t in range(H):
+            perm = feistel_perm.permutation(B, seed, stream, 0xFFFFFFFF if fixed else t)
+            slot_of_row = np.empty(B, dtype=np.int64)
+            slot_of_row[perm] = np.arange(B)
+            out[t] = slot_of_row[head_rows] // (B // M)
+        return torch.from_numpy(out)
+    r = meta["row_tiles"]
+    nwg = device_draws.fast_workgroups(B, r)
+    sched = device_draws.member_schedule(1 if fixed else H, nwg, M, seed, stream, fixed=fixed, iid=om.ensemble_kind == "basic_ensemble")
+    wg = device_draws.fast_row_workgroup(np.arange(B), P, r)[head_rows]
+    return torch.from_numpy(np.stack([sched[0 if fixed else t][wg] for t in range(H)]).astype(np.int64))
+
+
+@pytest.mark.parametrize("key", _plan_pins() or [None])
+def test_plans_entries_replayed_from_their_pin_records(key):
+    if key is None:
+        pytest.fail("tests/golden/oracle_cache/plans_full_size.npz holds no pin records: re-record it (profiles/session_r6_memo.sh)")
+    from test_gpu_plans_full_size import make_case
+
+    g = _plans_group()
+    meta = json.loads(bytes(g.data[key + oc.PIN_META]).decode())
+    head = torch.from_numpy(g.data[key + oc.PIN_HEAD])
+    stored = torch.from_numpy(g.data[key])
+    c, om, s0 = make_case(meta["case"])
+    P, H, pop = meta["P"], meta["H"], meta["pop"]
+    assert stored.shape == (pop,) and head.shape[1:] == (H, c["act"]) and 1 <= head.shape[0] <= pop
+    n = head.shape[0]
+    B = pop * P
+    head_rows = np.arange(n * P)  # batch row c * P + p: the head's candidates own the first n * P rows
+    members = _head_members(meta, om, head_rows, B)
+    eps = torch.from_numpy(device_draws.fast_normals(H, B, om.out_size, meta["seed"], meta["stream"], rows=head_rows))
+    fresh = po.rollout(om, head, s0, P, members=members, eps=eps).double()
+    want = stored[:n].double()
+    err = (fresh - want).abs()
+    tol = 1e-4 * torch.clamp(want.abs(), min=1.0)
+    bad = err > tol
+    if om.reward in ("cartpole", "inverted_pendulum") or om.termination not in (None, "none", "no_termination"):
+        # threshold functions: an eps difference of 1e-7 may flip one row's step: that candidate's return moves by k / P
+        assert int(bad.sum()) <= 1 and float(err.max()) <= 3.0 / P + 1e-4, f"{int(bad.sum())} of {n} head candidates beyond T2, max {err.max():.3e}"
+        return
+    assert not bad.any(), f"max |stored - fresh| {err.max():.3e} (T2 bound {tol[err.argmax()]:.3e}): {meta}"
