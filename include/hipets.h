@@ -133,7 +133,8 @@ typedef struct {
     float* trace_rewards;    /* [H,B] reward of the step before termination masking               */
     int32_t rows_per_group;  /* 0 = auto; else force R (row tiles of 16 per workgroup)            */
     int64_t* phase_cycles;   /* DEVICE [8,16] optional: per-wave, per-phase shader-cycle counters of     */
-                             /*   workgroup 0, accumulated (profiling aid)                */
+                             /*   workgroup 0, accumulated (profiling aid): cycles in the  */
+                             /*   low 44 bits of an entry, the number of marks that fed it above them    */
     int32_t no_sample;       /* FAST: predictions are the mean (no eps), like ModelEnv.step(sample=False) */
     int32_t rows_per_member; /* EXACT, > 0: explicit per-row member maps.  perms is [H, M*rows_per_member]             */
                              /*   ([M*rows_per_member] for fixed_model): slot m*rows_per_member + j = j-th row of        */
@@ -479,6 +480,8 @@ typedef struct {
     float* trace_latent;     /* optional DEVICE taps: [H,B,latent], [H,B,belief], [H,B]                          */
     float* trace_belief;
     float* trace_rewards;
+    int64_t* phase_cycles;   /* ABI v6: DEVICE [8,16] phase accumulators of workgroup 0, as hipets_rollout_opts.phase_cycles;    */
+                             /*   filled by profiling builds (-DHIPETS_LEAN_PROF=1) only, ignored by the shipped library         */
 } hipets_planet_opts;
 /* ModelEnv.evaluate_action_sequences on a PlaNetModel with no_termination and the learned reward head
  * (model_env.py:145-191, mbrl/algorithms/planet.py): actions DEVICE [pop,H,A]; latent0 / belief0 DEVICE [latent] /

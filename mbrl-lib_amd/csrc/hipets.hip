@@ -1711,6 +1711,7 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     ra.trace_latent = o->trace_latent;
     ra.trace_belief = o->trace_belief;
     ra.trace_rewards = o->trace_rewards;
+    ra.phase_cycles = reinterpret_cast<long long*>(o->phase_cycles);
     const size_t lds = planet_smem_bytes(e->pd.ld);
     const int nwg = (int)((B + kTile - 1) / kTile);
     // (HIPETS_PLANET_GENERIC=1: the run-time generic instance whatever the shapes -- tests compare the two bit for bit)

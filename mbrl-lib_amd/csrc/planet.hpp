@@ -37,8 +37,16 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld = pd.ld;
+    // phase profiler (rollout.hpp Prof; the marks inside the linear ops are wave_gemm's own): profiling builds only, workgroup 0
+    __shared__ long long prof_slots[kWaves * 16];
     Prof prof;
-    prof.on = false; prof.slot = nullptr; prof.t = 0;
+    prof.on = HIPETS_LEAN_PROF && ra.phase_cycles != nullptr && blockIdx.x == 0 && lane == 0;
+    prof.slot = prof_slots + wave * 16;
+    if (prof.on) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prof.slot[i] = 0;
+    }
+    prof.t = prof.on ? clock64() : 0;
 
     if (tid < kPlanetOps) ops[tid] = pd.ops[tid];
     if (tid < kTile) {
@@ -69,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
     };
     load_input(0);
     __syncthreads();
+    prof.mark(0);
 
     float* Cs = rows + pd.segC;
     float* Ds = rows + pd.segD;
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
         // reward head (E -> B -> C -> D) | accumulate, next input
         for (int i = 0; i < kPlanetOps; ++i) {
             const PlanetOp op = ops[i];
+            prof.mark(12);
             if constexpr (STATIC) {
                 // one shape-specialised instantiation per DISTINCT (column tiles, k chunks) pair: six for the eight ops
                 using PS = PlanetConfShape;
@@ -146,12 +156,15 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
             }
             if (op.post == PL_POST_NONE) continue;  // the next op touches other segments: same barrier interval
             __syncthreads();
+            prof.mark(8);
             if (op.post == PL_POST_GRU) {
                 gru(t);
                 __syncthreads();
+                prof.mark(9);
             } else if (op.post == PL_POST_SAMPLE) {
                 sample(t);
                 __syncthreads();
+                prof.mark(9);
             } else if (op.post == PL_POST_REWARD) {
                 if (tid < kTile) {  // model_env.py:186-188 with no_termination
                     const float r = Ds[tid * ld];
@@ -161,8 +174,13 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
                 }
                 if (t + 1 < ra.H) load_input(t + 1);
                 __syncthreads();
+                prof.mark(10);
             }
         }
+    }
+    if (prof.on) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ra.phase_cycles[wave * 16 + i] += prof.slot[i];
     }
     if (tid < kTile && rowid[tid] >= 0) ra.totals[rowid[tid]] = tot[tid];
 }

@@ -41,6 +41,7 @@ struct PlanetArgs {
     float* trace_latent;   // optional [H,B,latent]
     float* trace_belief;   // optional [H,B,belief]
     float* trace_rewards;  // optional [H,B]
+    long long* phase_cycles;  // optional [kWaves][16] phase accumulators of workgroup 0 (rollout.hpp Prof; -DHIPETS_LEAN_PROF=1 builds only)
 };
 
 // The shapes of conf/dynamics_model/planet.yaml (latent 30, belief 200, hidden 200, action 6 -- every planet_*.yaml override the

@@ -157,7 +157,10 @@ __device__ __forceinline__ int lds_col(int c) { return (c & ~15) | ((c & 3) << 2
 // phase profiler: lane 0 of every wave of workgroup 0 accumulates s_memtime deltas per phase in LDS (a mark is one LDS
 // read-modify-write on one lane, ~100 cycles; accumulating straight into global memory cost a ~800-cycle round trip per
 // mark and dominated the short phases it measured) and flushes them into RolloutArgs::phase_cycles[wave][phase] at the end
-// of the launch (a profiling aid, off unless the caller passes a buffer)
+// of the launch (a profiling aid, off unless the caller passes a buffer).  An accumulator holds the cycles in its low 44 bits and
+// the NUMBER of marks that fed it above them (round 6): a reader divides both by the step count and can subtract what the marks
+// themselves cost (profiles/one_tile_phase_profile.py calibrates that against the unprofiled launch duration).
+constexpr int kProfCountShift = 44;
 struct Prof {
     long long* slot;  // LDS: this wave's 16 accumulators
     long long t;
@@ -165,7 +168,7 @@ struct Prof {
     __device__ __forceinline__ void mark(int phase) {
         if (on) {
             const long long now = clock64();
-            slot[phase] += now - t;
+            slot[phase] += (now - t) + (1ll << kProfCountShift);
             t = now;
         }
     }

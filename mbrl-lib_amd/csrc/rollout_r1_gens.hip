@@ -1,0 +1,5 @@
+// rollout_r1_gens.hip -- rollout_kernel with R = 1 row tiles (16 rows each) per workgroup (rollout.hpp): the fully generic instance with the SiLU epilogue.
+// One of the four translation units of this R (rollout_inst.inc HIPETS_PART): they compile in parallel.
+#define HIPETS_R 1
+#define HIPETS_PART 4
+#include "rollout_inst.inc"

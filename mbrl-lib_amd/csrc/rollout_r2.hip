@@ -1,7 +1,5 @@
-// rollout_r2.hip -- rollout_kernel with R = 2 row tiles (16 rows each) per workgroup; see rollout.hpp.  This unit: the launcher and every
-// instance but the FAST-mode shape-specialised ones (rollout_r2_fast.hip; rollout_inst.inc HIPETS_PART).
+// rollout_r2.hip -- rollout_kernel with R = 2 row tiles (16 rows each) per workgroup (rollout.hpp): the launcher, the reference-semantics shape-specialised instances and the hidden-static instance.
+// One of the four translation units of this R (rollout_inst.inc HIPETS_PART): they compile in parallel.
 #define HIPETS_R 2
 #define HIPETS_PART 1
-#define HIPETS_LAUNCH_FN launch_rollout_r2
-#define HIPETS_LAUNCH_FAST_FN launch_rollout_r2_fast
 #include "rollout_inst.inc"

@@ -1,0 +1,5 @@
+// rollout_r2_gens.hip -- rollout_kernel with R = 2 row tiles (16 rows each) per workgroup (rollout.hpp): the fully generic instance with the SiLU epilogue.
+// One of the four translation units of this R (rollout_inst.inc HIPETS_PART): they compile in parallel.
+#define HIPETS_R 2
+#define HIPETS_PART 4
+#include "rollout_inst.inc"

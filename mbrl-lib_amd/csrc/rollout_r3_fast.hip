@@ -1,7 +1,5 @@
-// rollout_r3_fast.hip -- the FAST-mode shape-specialised instances of rollout_kernel with R = 3 row tiles per workgroup (the other
-// half of rollout_r3.hip: the two compile in parallel; rollout_inst.inc HIPETS_PART).
+// rollout_r3_fast.hip -- rollout_kernel with R = 3 row tiles (16 rows each) per workgroup (rollout.hpp): the FAST-mode shape-specialised instances.
+// One of the four translation units of this R (rollout_inst.inc HIPETS_PART): they compile in parallel.
 #define HIPETS_R 3
 #define HIPETS_PART 2
-#define HIPETS_LAUNCH_FN launch_rollout_r3
-#define HIPETS_LAUNCH_FAST_FN launch_rollout_r3_fast
 #include "rollout_inst.inc"

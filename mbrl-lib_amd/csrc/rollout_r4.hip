@@ -1,5 +1,5 @@
-// rollout_r4.hip -- rollout_kernel with R = 4 row tiles (16 rows each) per workgroup; see rollout.hpp.  (Seven instances: one unit.)
+// rollout_r4.hip -- rollout_kernel with R = 4 row tiles (16 rows each) per workgroup (rollout.hpp): the launcher, the reference-semantics shape-specialised instances and the hidden-static instance.
+// One of the four translation units of this R (rollout_inst.inc HIPETS_PART): they compile in parallel.
 #define HIPETS_R 4
-#define HIPETS_PART 0
-#define HIPETS_LAUNCH_FN launch_rollout_r4
+#define HIPETS_PART 1
 #include "rollout_inst.inc"

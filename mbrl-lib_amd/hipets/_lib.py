@@ -93,7 +93,7 @@ class PlanetDesc(C.Structure):
 
 class PlanetOpts(C.Structure):
     _fields_ = [("eps", C.c_void_p), ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("no_sample", C.c_int32),
-                ("trace_latent", C.c_void_p), ("trace_belief", C.c_void_p), ("trace_rewards", C.c_void_p)]
+                ("trace_latent", C.c_void_p), ("trace_belief", C.c_void_p), ("trace_rewards", C.c_void_p), ("phase_cycles", C.c_void_p)]
 
 
 # every symbol include/hipets.h declares: name -> (restype, argtypes)

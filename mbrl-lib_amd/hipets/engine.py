@@ -647,7 +647,8 @@ class Engine:
     def planet_rollout(self, actions: torch.Tensor, latent0: torch.Tensor, belief0: torch.Tensor, num_particles: int, *,
                        eps: Optional[torch.Tensor] = None, sample: bool = True, seed: int = 0, stream_id: int = 0,
                        trace_latent: Optional[torch.Tensor] = None, trace_belief: Optional[torch.Tensor] = None,
-                       trace_rewards: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       trace_rewards: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                       phase_cycles: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ModelEnv.evaluate_action_sequences on the PlaNet model (model_env.py:145-191): actions [pop, H, A]; latent0 /
         belief0 = the saved posterior sample / belief ([latent] / [belief], any leading 1s) on the device."""
         spec = getattr(self, "planet_spec", None)
@@ -674,6 +675,9 @@ class Engine:
             if t is not None:
                 _check_dev(t, torch.float32, dev, name, (H, B) if width is None else (H, B, width))
                 setattr(o, name, _ptr(t))
+        if phase_cycles is not None:  # (filled by -DHIPETS_LEAN_PROF=1 builds only: profiles/one_tile_phase_profile.py)
+            _check_dev(phase_cycles, torch.int64, dev, "phase_cycles", (8, 16))
+            o.phase_cycles = _ptr(phase_cycles)
         if out is None:
             out = torch.empty(pop, dtype=torch.float32, device=dev)
         else:
