@@ -37,8 +37,10 @@ __global__ __launch_bounds__(kThreads) void planet_rollout_kernel(const PlanetDe
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld = pd.ld;
-    // phase profiler (rollout.hpp Prof; the marks inside the linear ops are wave_gemm's own): profiling builds only, workgroup 0
-    __shared__ long long prof_slots[kWaves * 16];
+    // phase profiler (rollout.hpp Prof; the marks inside the linear ops are wave_gemm's own): profiling builds only, workgroup 0.
+    // (Its accumulators sit at the end of the DYNAMIC LDS: the kernel opts in to the full 160 KB of dynamic LDS, and a static array on
+    // top of that made the launch fail with "invalid argument".)
+    long long* const prof_slots = reinterpret_cast<long long*>(smem_raw + planet_smem_bytes(pd.ld) - kWaves * 16 * sizeof(long long));
     Prof prof;
     prof.on = HIPETS_LEAN_PROF && ra.phase_cycles != nullptr && blockIdx.x == 0 && lane == 0;
     prof.slot = prof_slots + wave * 16;

@@ -63,7 +63,8 @@ inline bool planet_static_shape(const PlanetDev& pd, const PlanetOp* host_ops) {
 }
 
 __host__ __device__ inline size_t planet_smem_bytes(int ld) {
-    return (size_t)kTile * ld * 4 + 2 * kTile * 4 + sizeof(PlanetOp) * kPlanetOps;
+    const size_t n = (size_t)kTile * ld * 4 + 2 * kTile * 4 + sizeof(PlanetOp) * kPlanetOps;
+    return (n + 7) / 8 * 8 + kWaves * 16 * sizeof(long long);  // ... + the phase profiler's accumulators (profiling builds; 512 bytes)
 }
 
 }  // namespace hipets

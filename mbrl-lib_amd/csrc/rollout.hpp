@@ -224,6 +224,16 @@ __device__ __forceinline__ void pair_load_issue(u32x4g& d, const unsigned long l
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS-DMA of 64 hand-over pairs (one per lane, device-scope loads like pair_load_issue) straight into LDS: lane l's 16 bytes land at
+// LDS byte address lds_dst + 16 l (lds_dst wave-uniform), no destination registers.  Counted on vmcnt; the compiler does not know
+// (cdna_hip_programming.md: M0 is written and restored inside the statement that reads it; the s_nop is the SALU-write -> M0-read
+// state).  Data is visible to a ds_read of the ISSUING wave after its own s_waitcnt vmcnt(0) (MI355X_MICROARCH.md item 7).
+__device__ __forceinline__ void pair_dma_issue(const unsigned long long* gsrc, const unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void prefetch_issue(const NextOp& n, const int lane, Pre& pre) {
     if (!n.valid) return;
     const char* Wb = reinterpret_cast<const char*>(n.W);
@@ -1585,14 +1595,25 @@ struct RolloutSmem {
     float* dump;     // [4] sink of the fused tail's masked-off LDS stores (branch-free: an inactive lane stores here)
     float* part;     // one-tile workgroups: [2][kWaves][64][4] k-split partial sums (KsArgs)
     float* expacc;   // [ROWS][out_total] (expectation propagation only)
+    char* stage_x;   // KSpec::WIDE: the chunks of the hand-over staging area that do not fit buf0 + buf1 (dma_stage_extra_bytes; last section)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // ld0 > 0: buf0 has its own row stride (KSpec::WIDE: the model-input image), buf1 uses `ld`
+// KSpec::WIDE instances collect a turn's rows by LDS-DMA (rollout_kernel, "dma_collect"): rows x pairs 16-byte hand-over pairs staged
+// in 1 KiB chunks of 64.  The two activation buffers are idle then and hold most of them; what does not fit gets a section of its own.
+__host__ __device__ inline size_t dma_stage_extra_bytes(int rows, int ld, int ld0, int obs_dim) {
+    const size_t pairs = (size_t)rows * ((obs_dim + 1) / 2 + 1);
+    const size_t need = (pairs + 63) / 64 * 1024;
+    const size_t have = ((size_t)rows * ld0 * 4 + 15) / 16 * 16 + ((size_t)rows * ld * 4 + 15) / 16 * 16;
+    return need > have ? need - have : 0;
+}
+
 __host__ __device__ inline size_t rollout_smem_bytes(int rows, int ld, int obs_dim, int act_dim, int in_dim, int out_dim,
                                                      int out_total, int horizon, bool expectation, int lv_rows = 1, int ld0 = 0) {
     size_t n = 0;
+    if (ld0 > 0) n += dma_stage_extra_bytes(rows, ld, ld0, obs_dim);  // (ld0 > 0: the KSpec::WIDE layout)
     n += align16((size_t)rows * (ld0 > 0 ? ld0 : ld) * 4) + align16((size_t)rows * ld * 4);
     n += align16((size_t)rows * obs_dim * 4);
     n += align16((size_t)2 * rows * act_dim * 4);
@@ -1690,6 +1711,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         sm.nodelta = reinterpret_cast<int*>(p); p += align16((size_t)md.obs_dim * 4);
         sm.sched = reinterpret_cast<int*>(p); p += align16((size_t)ra.H * 4);
         sm.expacc = reinterpret_cast<float*>(p);
+        sm.stage_x = p;  // (KSpec::WIDE instances have no expectation accumulator: the extra staging chunks are the last section)
 #if HIPETS_DEBUG_BOUNDS
         {   // every section starts inside the launch's dynamic LDS, 16-byte aligned, in layout order; the last one ends inside it
             const char* const secs[] = {(char*)sm.buf0, (char*)sm.buf1, (char*)sm.tot, (char*)sm.lrew, (char*)sm.term, (char*)sm.rowid, (char*)sm.pend,
@@ -1814,6 +1836,16 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #define HIPETS_COLLECT_OUT4 4
 #endif
     constexpr int kGT = S::WIDE ? HIPETS_COLLECT_WIDE : ((kLean && S::OUTC >= 4) ? HIPETS_COLLECT_OUT4 : kG);
+    // Round 6, KSpec::WIDE (cfg4', Humanoid-v4: 189 pairs per row, 6 048 per two-tile workgroup and turn): the rows of a turn are fetched
+    // by LDS-DMA -- no destination registers, so ALL of a wave's ~24 KiB are in flight at once (the register path above manages 8 pairs
+    // per thread and needs three round trips of ~3 us) -- into the activation buffers, which are idle between two turns, and validated
+    // LDS -> LDS by the wave that issued them (dma_collect below).  Every persistent launch of the instance takes the turn-based flow
+    // then, also when each workgroup serves one logical workgroup (the straight form's collect writes the input image while it polls:
+    // the image IS the staging area here).
+#ifndef HIPETS_DMA_COLLECT
+#define HIPETS_DMA_COLLECT 1
+#endif
+    constexpr bool kDmaCollect = S::WIDE && HIPETS_DMA_COLLECT;
     int xs[kG], xv[kG];
 #pragma unroll
     for (int q = 0; q < kG; ++q) {
@@ -2190,7 +2222,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #ifdef HIPETS_DBG_NOSTRAIGHT
     const bool straight = false;
 #else
-    const bool straight = kFuse && persist && ra.n_logical == (int)gridDim.x && md.n_layers >= 4;
+    const bool straight = kFuse && !kDmaCollect && persist && ra.n_logical == (int)gridDim.x && md.n_layers >= 4;
 #endif
     int* const rows_a = sm.rowid;
     int* const rows_b = sm.pend + ROWS;
@@ -2286,6 +2318,84 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         }
         HIPETS_STAMP(2, t_next - 1);  // this thread's rows have arrived
     };
+    // ---- KSpec::WIDE: collect the rows `sm.rowid` names (published with tag `want`) by LDS-DMA ---------------------------------------
+    // Item i = (row slot i / NVP, pair i % NVP) as in the register path; chunk c = items [64 c, 64 c + 64) = 1 KiB of staging, owned by
+    // wave c % kWaves from issue to commit: the wave's own s_waitcnt vmcnt(0) is all that orders its ds_reads behind its DMAs (no
+    // barrier).  A chunk with a lane whose pair has not been published yet (its tags are an earlier step's) is fetched again; only a
+    // step's first turn can see that.  The {running total, flag} pair of a row gets one look per pass and is left to the next tail if
+    // late (sm.pend), exactly like the register path.
+    auto dma_collect = [&](const unsigned want) __attribute__((always_inline)) {
+        const int n_items = ROWS * NVP;
+        const int n_chunks = (n_items + 63) >> 6;
+        const int n_main = (int)((align16((size_t)ROWS * ld_in * 4) + align16((size_t)ROWS * ld_k * 4)) >> 10);  // chunks that fit buf0 + buf1 (contiguous)
+        char* const stage0 = reinterpret_cast<char*>(sm.buf0);
+        HIPETS_BOUND((n_chunks + kWaves - 1) / kWaves <= 32 && (size_t)(n_chunks - n_main) * 1024 <= dma_stage_extra_bytes(ROWS, ld_k, ld_in, md.obs_dim) + 1023);
+        auto chunk_ptr = [&](const int c) __attribute__((always_inline)) { return c < n_main ? stage0 + ((size_t)c << 10) : sm.stage_x + ((size_t)(c - n_main) << 10); };
+        auto item_src = [&](const int c, int& s, int& v, bool& live) __attribute__((always_inline)) {
+            const int i = (c << 6) + lane;
+            const int i_row = (int)__umulhi((unsigned)i, nvp_magic);  // (exact for i < 2^32 / NVP)
+            s = i < n_items ? i_row : -1;
+            v = i < n_items ? i - i_row * NVP : 0;
+            live = false;
+            const unsigned long long* src = ra.exchange;  // lanes with nothing to fetch read the table's first pair and ignore it
+            if (s >= 0) {
+                const int rid = sm.rowid[s];
+                if (rid >= 0) { src = ra.exchange + (size_t)rid * NV + 2 * v; live = true; }
+            }
+            return src;
+        };
+        for (int c = wave; c < n_chunks; c += kWaves) {
+            int s, v;
+            bool live;
+            const unsigned long long* src = item_src(c, s, v, live);
+            pair_dma_issue(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)chunk_ptr(c)));
+        }
+        unsigned pending = 0xFFFFFFFFu;  // bit k: this wave's k-th chunk (chunk wave + k kWaves) still has a lane waiting
+        const long long t_poll = wall_clock64();
+        for (int spins = 0;; ++spins) {
+            vmem_drain();  // this wave's DMAs have landed
+            unsigned still = 0;
+            for (int k = 0, c = wave; c < n_chunks; ++k, c += kWaves) {
+                if (!((pending >> k) & 1u)) continue;  // (wave-uniform)
+                int s, v;
+                bool live;
+                const unsigned long long* src = item_src(c, s, v, live);
+                const u32x4g g = *reinterpret_cast<const u32x4g*>(chunk_ptr(c) + lane * 16);
+                const bool soft = v == NVP - 1;
+                const bool ok = !live || (g[1] == want && g[3] == want);
+                if (s >= 0) {
+                    HIPETS_BOUND(s < ROWS && v >= 0 && v < NVP);
+                    if (!soft) {
+                        if (ok) {
+                            const int d = 2 * v;
+                            sm.state[s * md.obs_dim + d] = live ? __uint_as_float(g[0]) : 0.f;
+                            if (d + 1 < md.obs_dim) sm.state[s * md.obs_dim + d + 1] = live ? __uint_as_float(g[2]) : 0.f;
+                        }
+                    } else if (ok) {
+                        sm.tot[s] = live ? __uint_as_float(g[0]) : 0.f;
+                        sm.term[s] = live ? (int)g[2] : 0;
+                        sm.pend[s] = 0;
+                    } else {
+                        sm.pend[s] = 1;  // not there yet: the next tail fetches the pair
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(live && !ok && !soft) != 0) {  // somebody's state pair is still an earlier step's: fetch the chunk again
+                    still |= 1u << k;
+                    pair_dma_issue(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)chunk_ptr(c)));
+                }
+            }
+            pending = still;
+            if (!pending) break;
+            if ((poll_every || (spins & 63) == 63) && (wall_clock64() - t_poll > ra.poll_ticks || *(volatile int*)ra.error_flag)) {
+                *ra.error_flag = 1;
+                vmem_drain();  // nothing of this wave may still be landing in the activation buffers when the flow goes on
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    (void)dma_collect;
+
     for (int q_seq = 0; q_seq < n_seq; ++q_seq) {
         stamp_seq = q_seq;
         const int t = ra.t_begin + q_seq / n_serve;
@@ -2738,6 +2848,8 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     sm.tot[s_] = 0.f;
                     sm.term[s_] = 0;
                 }
+            } else if constexpr (kDmaCollect) {
+                dma_collect((unsigned)(tag >> 32));
             } else
             for (int base = 0; base < ROWS * NVP; base += kGT * kThreads) {
                 const unsigned long long* src[kGT];
