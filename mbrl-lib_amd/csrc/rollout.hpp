@@ -2482,7 +2482,13 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const double nmA = q.nmA, nmB = q.nmB, nsA = q.nsA, nsB = q.nsB;
                 // the two normals of (row, step, dims d0, d0 + 1): half of Philox block d0 / 4, exactly rollout_normals4's
                 float n0, n1;
-                {
+#ifndef HIPETS_TIMING_NO_DRAWS
+#define HIPETS_TIMING_NO_DRAWS 0  // 1 = TIMING-ONLY builds (results are wrong on purpose): the tail draws nothing -- an upper bound of what moving
+#endif                            // the draws off the step's critical path (e.g. into the hand-over wait) could gain; profiles/headline_probe.py
+                if constexpr (HIPETS_TIMING_NO_DRAWS) {
+                    n0 = 0.37f + 1e-3f * (float)(rid & 7);
+                    n1 = -0.81f;
+                } else {
                     const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)(d0 >> 2), (uint32_t)ra.stream_id, (uint32_t)ra.seed,
                                                      (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32));
                     const bool upper = (d0 & 2) != 0;

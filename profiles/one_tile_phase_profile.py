@@ -48,6 +48,21 @@ def event_ms(fn, n=20, warm=5):
     return a.elapsed_time(b) / n
 
 
+def kernel_ms(fn, n=20, warm=5):
+    """average rollout-KERNEL duration (the engine's own events on the dispatch packets: no launch gaps, no particle-mean kernel)"""
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    eng.timing_enable(True)
+    eng.timing_read(reset=True)
+    for i in range(n):
+        fn(warm + i)
+    torch.cuda.synchronize()
+    cnt, ms = eng.timing_read(reset=True)
+    eng.timing_enable(False)
+    return ms / max(cnt, 1) * (cnt / n)  # (per rollout: one persistent launch, or H per-step launches)
+
+
 def decode(pc, H, unprofiled_ms, profiled_ms):
     pcs = pc.cpu().numpy().astype(np.int64)
     cyc, cnt = pcs & ((1 << SHIFT) - 1), pcs >> SHIFT
@@ -76,9 +91,9 @@ for name, obs, act, pop, H, P, rew in [("cfg1_cartpole (BASELINE configs[0]: pop
     rec = {}
     for mode in ("device", "fast"):
         cls = list(eng.kernel_class(pop, P, H, mode))
-        ums = event_ms(lambda i: eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=i))
+        ums = kernel_ms(lambda i: eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=i))
         pc = torch.zeros(8, 16, dtype=torch.int64, device=dev)
-        pms = event_ms(lambda i: eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=100 + i, phase_cycles=pc), n=10, warm=2)
+        pms = kernel_ms(lambda i: eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=100 + i, phase_cycles=pc), n=10, warm=2)
         pc.zero_()
         eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=999, phase_cycles=pc)
         torch.cuda.synchronize()
