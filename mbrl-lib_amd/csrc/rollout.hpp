@@ -1604,8 +1604,8 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // KSpec::WIDE instances collect a turn's rows by LDS-DMA (rollout_kernel, "dma_collect"): rows x pairs 16-byte hand-over pairs staged
 // in 1 KiB chunks of 64.  The two activation buffers are idle then and hold most of them; what does not fit gets a section of its own.
 __host__ __device__ inline size_t dma_stage_extra_bytes(int rows, int ld, int ld0, int obs_dim) {
-    const size_t pairs = (size_t)rows * ((obs_dim + 1) / 2 + 1);
-    const size_t need = (pairs + 63) / 64 * 1024;
+    const size_t nvp = (size_t)(obs_dim + 1) / 2 + 1;          // pairs per row
+    const size_t need = (size_t)rows * ((nvp + 63) / 64) * 1024;  // every row's pairs in whole chunks of 64 (dma_collect)
     const size_t have = ((size_t)rows * ld0 * 4 + 15) / 16 * 16 + ((size_t)rows * ld * 4 + 15) / 16 * 16;
     return need > have ? need - have : 0;
 }
@@ -2120,9 +2120,48 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             }
         }
     };
+    // KSpec::WIDE (cfg4': 32 rows x 400 input columns per pass; f64 normaliser, no obs preprocessing -- facts of the shape): the pass
+    // by COLUMN.  A thread owns columns tid, tid + 256, ... for every row: its normaliser constants and LDS position are loaded once
+    // per column, consecutive lanes read consecutive state floats (no bank conflict) and write the 64 positions of four whole k chunks
+    // (lds_col permutes inside a chunk: no conflict either).  The by-group items above read the four columns {16 kk + 4 q + g} per
+    // lane: lanes 16 columns apart meet on a bank -- 4-way conflicts on the state reads, 8-way on the f64 constants -- and the pass
+    // measured 7-8 us per turn in the step trace (profiles/r6_turn_trace.json: "arrived -> built"), a tenth of a cfg4' turn in BOTH
+    // modes.  Same arithmetic per element: same bits.
+#ifndef HIPETS_INPUT_BY_COLUMN
+#define HIPETS_INPUT_BY_COLUMN 1
+#endif
+    auto build_input_cols = [&](const int t, float* const dst) __attribute__((always_inline)) {
+        const float* actn_t = sm.actn + (t & 1) * n_act;
+        constexpr int kU = 8;  // rows per batch: the batch's LDS reads are issued together
+        static_assert(ROWS % kU == 0, "row batches");
+        for (int c = tid; c < Kp0; c += kThreads) {
+            const bool inb = c < md.in_dim;
+            const int cc = min(c, md.in_dim - 1);
+            const double nm = sm.nmean[cc], ns = sm.nstd[cc];
+            const bool from_state = cc < md.obs_in;
+            const float* const src = from_state ? sm.state + cc : actn_t + (cc - md.obs_in);
+            const int stride = from_state ? md.obs_dim : md.act_dim;
+            float* const out = dst + lds_col(c);
+            for (int s0_ = 0; s0_ < ROWS; s0_ += kU) {
+                float x[kU];
+                int rid[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    x[u] = src[(s0_ + u) * stride];
+                    rid[u] = sm.rowid[s0_ + u];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) out[(s0_ + u) * ld_in] = (inb && rid[u] >= 0) ? (float)(((double)x[u] - nm) * ns) : 0.f;
+            }
+        }
+    };
     auto build_input = [&](const int t, float* const dst) __attribute__((always_inline)) {
         using T = std::true_type;
         using F = std::false_type;
+        if constexpr (kWide && HIPETS_INPUT_BY_COLUMN) {  // (KSpec static_assert: WIDE instances have the f64 normaliser and no obs preprocessing)
+            build_input_cols(t, dst);
+            return;
+        }
         const bool plain = obs_process == HIPETS_OBS_NONE;
         switch (normalizer) {
             case HIPETS_NORM_F64:
@@ -2319,69 +2358,81 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         HIPETS_STAMP(2, t_next - 1);  // this thread's rows have arrived
     };
     // ---- KSpec::WIDE: collect the rows `sm.rowid` names (published with tag `want`) by LDS-DMA ---------------------------------------
-    // Item i = (row slot i / NVP, pair i % NVP) as in the register path; chunk c = items [64 c, 64 c + 64) = 1 KiB of staging, owned by
-    // wave c % kWaves from issue to commit: the wave's own s_waitcnt vmcnt(0) is all that orders its ds_reads behind its DMAs (no
-    // barrier).  A chunk with a lane whose pair has not been published yet (its tags are an earlier step's) is fetched again; only a
-    // step's first turn can see that.  The {running total, flag} pair of a row gets one look per pass and is left to the next tail if
-    // late (sm.pend), exactly like the register path.
+    // Wave w owns the row slots w, w + kWaves, ... from issue to commit: a row's NVP pairs are CPR = ceil(NVP / 64) chunks of 64 (1 KiB
+    // of staging each; slot s, chunk k sits at staging chunk s CPR + k), the row id is wave-uniform, a lane's source is the row's base +
+    // its pair -- no division, no per-lane row lookup (the first version dealt chunks of 64 CONSECUTIVE items to the waves and paid an
+    // LDS round trip for the row id and a multiply-high per chunk and lane: 12.2 us per collect against the register path's 9.6,
+    // profiles/r6_turn_trace.json).  The wave's own s_waitcnt vmcnt(0) is all that orders its ds_reads behind its DMAs (no barrier).  A
+    // chunk with a lane whose pair has not been published yet (its tags are an earlier step's) is fetched again; only a step's first
+    // turn can see that.  The {running total, flag} pair of a row gets one look per pass and is left to the next tail if late
+    // (sm.pend), exactly like the register path.
     auto dma_collect = [&](const unsigned want) __attribute__((always_inline)) {
-        const int n_items = ROWS * NVP;
-        const int n_chunks = (n_items + 63) >> 6;
+        // chunks per row: a compile-time fact of the WIDE shapes (47 output column tiles <=> obs 369..376 <=> 186..189 pairs <=> 3 chunks)
+        constexpr int CPR = kWide ? (((S::OUTC > 0 ? S::OUTC : 1) * 8 + 1) / 2 + 1 + 63) / 64 : 1;
+        constexpr int kRowsPerWave = ROWS / kWaves;
+        static_assert(ROWS % kWaves == 0 && kRowsPerWave * CPR <= 32, "row slots are dealt to the waves; one pending bit per (row, chunk)");
         const int n_main = (int)((align16((size_t)ROWS * ld_in * 4) + align16((size_t)ROWS * ld_k * 4)) >> 10);  // chunks that fit buf0 + buf1 (contiguous)
         char* const stage0 = reinterpret_cast<char*>(sm.buf0);
-        HIPETS_BOUND((n_chunks + kWaves - 1) / kWaves <= 32 && (size_t)(n_chunks - n_main) * 1024 <= dma_stage_extra_bytes(ROWS, ld_k, ld_in, md.obs_dim) + 1023);
+        HIPETS_BOUND(CPR == (NVP + 63) / 64 && (size_t)max(ROWS * CPR - n_main, 0) * 1024 <= dma_stage_extra_bytes(ROWS, ld_k, ld_in, md.obs_dim));
         auto chunk_ptr = [&](const int c) __attribute__((always_inline)) { return c < n_main ? stage0 + ((size_t)c << 10) : sm.stage_x + ((size_t)(c - n_main) << 10); };
-        auto item_src = [&](const int c, int& s, int& v, bool& live) __attribute__((always_inline)) {
-            const int i = (c << 6) + lane;
-            const int i_row = (int)__umulhi((unsigned)i, nvp_magic);  // (exact for i < 2^32 / NVP)
-            s = i < n_items ? i_row : -1;
-            v = i < n_items ? i - i_row * NVP : 0;
-            live = false;
-            const unsigned long long* src = ra.exchange;  // lanes with nothing to fetch read the table's first pair and ignore it
-            if (s >= 0) {
-                const int rid = sm.rowid[s];
-                if (rid >= 0) { src = ra.exchange + (size_t)rid * NV + 2 * v; live = true; }
+        auto lds_of = [&](const int c) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)chunk_ptr(c)); };
+        unsigned pending = 0;  // bit j CPR + k: chunk k of this wave's j-th row still has a lane waiting
+        int rids[kRowsPerWave];
+#pragma unroll
+        for (int j = 0; j < kRowsPerWave; ++j) rids[j] = sm.rowid[wave + kWaves * j];  // (all of the wave's row ids in one LDS round trip)
+#pragma unroll
+        for (int j = 0; j < kRowsPerWave; ++j) {
+            const int s = wave + kWaves * j;
+            const int rid = __builtin_amdgcn_readfirstlane(rids[j]);
+            rids[j] = rid;
+            if (rid >= 0) {
+                const unsigned long long* const row = ra.exchange + (size_t)rid * NV;
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) {
+                    const int v = min(64 * k + lane, NVP - 1);  // (lanes beyond the row's last pair fetch it again and ignore it)
+                    pair_dma_issue(row + 2 * v, lds_of(s * CPR + k));
+                }
+                pending |= ((1u << CPR) - 1u) << (j * CPR);
+            } else {  // a row of the padding: zero state, total, flag
+                for (int d = lane; d < md.obs_dim; d += 64) sm.state[s * md.obs_dim + d] = 0.f;
+                if (lane == 0) { sm.tot[s] = 0.f; sm.term[s] = 0; sm.pend[s] = 0; }
             }
-            return src;
-        };
-        for (int c = wave; c < n_chunks; c += kWaves) {
-            int s, v;
-            bool live;
-            const unsigned long long* src = item_src(c, s, v, live);
-            pair_dma_issue(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)chunk_ptr(c)));
         }
-        unsigned pending = 0xFFFFFFFFu;  // bit k: this wave's k-th chunk (chunk wave + k kWaves) still has a lane waiting
         const long long t_poll = wall_clock64();
-        for (int spins = 0;; ++spins) {
+        for (int spins = 0; pending; ++spins) {
             vmem_drain();  // this wave's DMAs have landed
             unsigned still = 0;
-            for (int k = 0, c = wave; c < n_chunks; ++k, c += kWaves) {
-                if (!((pending >> k) & 1u)) continue;  // (wave-uniform)
-                int s, v;
-                bool live;
-                const unsigned long long* src = item_src(c, s, v, live);
-                const u32x4g g = *reinterpret_cast<const u32x4g*>(chunk_ptr(c) + lane * 16);
-                const bool soft = v == NVP - 1;
-                const bool ok = !live || (g[1] == want && g[3] == want);
-                if (s >= 0) {
-                    HIPETS_BOUND(s < ROWS && v >= 0 && v < NVP);
-                    if (!soft) {
+#pragma unroll
+            for (int j = 0; j < kRowsPerWave; ++j) {
+                if (!((pending >> (j * CPR)) & ((1u << CPR) - 1u))) continue;  // (wave-uniform) nothing of this row is waiting
+                const int s = wave + kWaves * j;
+                u32x4g g[CPR];
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) g[k] = *reinterpret_cast<const u32x4g*>(chunk_ptr(s * CPR + k) + lane * 16);  // the row's chunks in one LDS round trip
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) {
+                    if (!((pending >> (j * CPR + k)) & 1u)) continue;  // (wave-uniform)
+                    const int v = 64 * k + lane;
+                    const bool mine = v < NVP, soft = v == NVP - 1;
+                    const bool ok = g[k][1] == want && g[k][3] == want;
+                    HIPETS_BOUND(s < ROWS);
+                    if (mine && !soft) {
                         if (ok) {
                             const int d = 2 * v;
-                            sm.state[s * md.obs_dim + d] = live ? __uint_as_float(g[0]) : 0.f;
-                            if (d + 1 < md.obs_dim) sm.state[s * md.obs_dim + d + 1] = live ? __uint_as_float(g[2]) : 0.f;
+                            sm.state[s * md.obs_dim + d] = __uint_as_float(g[k][0]);
+                            if (d + 1 < md.obs_dim) sm.state[s * md.obs_dim + d + 1] = __uint_as_float(g[k][2]);
                         }
-                    } else if (ok) {
-                        sm.tot[s] = live ? __uint_as_float(g[0]) : 0.f;
-                        sm.term[s] = live ? (int)g[2] : 0;
-                        sm.pend[s] = 0;
-                    } else {
-                        sm.pend[s] = 1;  // not there yet: the next tail fetches the pair
+                    } else if (soft) {
+                        if (ok) {
+                            sm.tot[s] = __uint_as_float(g[k][0]);
+                            sm.term[s] = (int)g[k][2];
+                        }
+                        sm.pend[s] = ok ? 0 : 1;  // not there yet: the next tail fetches the pair
                     }
-                }
-                if (__builtin_amdgcn_ballot_w64(live && !ok && !soft) != 0) {  // somebody's state pair is still an earlier step's: fetch the chunk again
-                    still |= 1u << k;
-                    pair_dma_issue(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)chunk_ptr(c)));
+                    if (__builtin_amdgcn_ballot_w64(mine && !soft && !ok) != 0) {  // somebody's state pair is still an earlier step's: fetch the chunk again
+                        still |= 1u << (j * CPR + k);
+                        pair_dma_issue(ra.exchange + (size_t)rids[j] * NV + 2 * min(v, NVP - 1), lds_of(s * CPR + k));
+                    }
                 }
             }
             pending = still;
