@@ -642,7 +642,7 @@ int hipets_fast_geometry(hipets_engine* e, int32_t pop, int32_t P, int32_t horiz
     if (rows_per_group < -1 || rows_per_group > kMaxR) return fail("rows_per_group outside [-1, %d]", kMaxR);
     const long long tiles = fast_tiles(pop, P);
     const bool wide = rows_per_group >= 0 && rows_per_group <= 2 && wide_model(e->md);  // a default call runs the WIDE instance there
-    const int R = choose_R(e, tiles, 1, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide, true);
+    const int R = choose_R(e, tiles, 1, rows_per_group < 0 ? 0 : rows_per_group, horizon, wide, horizon > 1);  // (one step: nothing drifts apart, hipets_step)
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
     const long long groups = (tiles + R - 1) / R;
     if (n_workgroups) *n_workgroups = (int)groups;
@@ -676,7 +676,7 @@ int hipets_kernel_class(hipets_engine* e, int32_t pop, int32_t P, int32_t horizo
         slices = 1;
     }
     const bool wide = wide_model(md) && call_lean && rows_per_group <= 2;
-    const int R = choose_R(e, tiles, slices, rows_per_group, horizon, wide, mode == HIPETS_MODE_FAST);
+    const int R = choose_R(e, tiles, slices, rows_per_group, horizon, wide, mode == HIPETS_MODE_FAST && horizon > 1);
     if (lds_for(e, R, horizon, wide) > e->lds_max) return fail("the model does not fit LDS");
     int cls = HIPETS_KERNEL_GENERIC;
     if (md.precision == HIPETS_PREC_BF16X3) {
@@ -904,7 +904,7 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
                         "the wide-output instance's: size member_schedule with hipets_fast_geometry(rows_per_group = -1) and pass its row-tile "
                         "count as opts->rows_per_group");
         ra.wide_lds = wide ? 1 : 0;
-        const int R = choose_R(e, tiles, 1, o->rows_per_group, H, wide, true);
+        const int R = choose_R(e, tiles, 1, o->rows_per_group, H, wide, H > 1);
         const size_t lds = lds_for(e, R, H, wide);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int groups = (int)((tiles + R - 1) / R);
@@ -1083,7 +1083,7 @@ int hipets_step(hipets_engine* e, const float* obs, const float* actions, int32_
         // with per-row initial states, which only the generic / hidden-static instances have, behind a member-schedule kernel that
         // ranked all workgroups' sort keys: a 100 000-row call took 0.44 ms where DEVICE mode took 0.34.)
         const long long tiles = (B + kTile - 1) / kTile;
-        const int R = choose_R(e, tiles, 1, o->rows_per_group, 1, false, true);
+        const int R = choose_R(e, tiles, 1, o->rows_per_group, 1, false, false);  // (a single step: two workgroups on a CU do not drift apart -- priced like DEVICE's)
         const size_t lds = lds_for(e, R, 1);
         if (lds > e->lds_max) return fail("rows_per_group %d does not fit LDS", R);
         const int nwg = (int)((tiles + R - 1) / R);
