@@ -1,4 +1,4 @@
-"""The bench line the repository ships (profiles/r5_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
+"""The bench line the repository ships (profiles/r6_bench_line.json = the last `python bench.py` on an MI355X) obeys the driver's
 contract and is internally consistent: the roofline block follows from the algorithmic FLOP count and the measured launch
 time, `value` from the plan time, the metric / workload are BASELINE.json's.  (CPU test: reads committed files only.)"""
 import json
@@ -10,7 +10,7 @@ from conftest import ROOT
 
 
 def _line():
-    return json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r6_bench_line.json")))
 
 
 def test_contract_keys_and_types():
@@ -46,14 +46,16 @@ def test_roofline_block_is_consistent():
 
 
 def test_rocprof_summary_agrees_with_the_live_measurement():
-    """profiles/r5_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
+    """profiles/r6_kernel_stats_device.csv (rocprofv3 --kernel-trace --stats of the same command) within 2 % of avg_launch_ms."""
     import csv
 
     r = _line()["roofline"]
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_kernel_stats_device.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r6_kernel_stats_device.csv"))))
     roll = [x for x in rows if "rollout_kernel" in x["Name"]]
     assert roll, "no rollout kernel in the committed rocprofv3 statistics"
-    avg_ms = float(roll[0]["AverageNs"]) * 1e-6
+    # (116 calls = 115 rollouts + the one co-residency self-test launch of a few microseconds: taken out of the average)
+    calls, total, mn = int(roll[0]["Calls"]), float(roll[0]["TotalDurationNs"]), float(roll[0]["MinNs"])
+    avg_ms = ((total - mn) / (calls - 1) if mn < 0.05 * total / calls else total / calls) * 1e-6
     assert avg_ms == pytest.approx(r["avg_launch_ms"], rel=0.02)
     traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     # (the line reads the committed file as it was when bench.py ran; the round's own PMC passes rewrote it afterwards: 139.5 -> 139.9 MB)
@@ -86,12 +88,12 @@ def test_stock_defaults_block_prices_the_shipped_workloads_with_their_own_flop_c
     assert hc["fast"]["roofline"]["frac"] >= 0.95 * d["fast_mode"]["roofline"]["frac"]
     for w, name in ((hc, "stock_halfcheetah"), (cp, "stock_cartpole")):
         for mode in ("device", "fast"):
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r4_{name}_kernel_stats_{mode}.csv"))))
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r6_{name}_kernel_stats_{mode}.csv"))))
             roll = [x for x in rows if "rollout_kernel" in x["Name"]]
             assert roll and float(roll[0]["Percentage"]) > 90
             assert float(roll[0]["AverageNs"]) * 1e-6 == pytest.approx(w[mode]["roofline"]["avg_launch_ms"], rel=0.03)
     # the instances that ran: obs preprocessing is part of the shape (KSpec<act, hidC, outC, norm, OBSP, rew, term, mode, prec, fuse>)
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_stock_halfcheetah_kernel_stats_device.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r6_stock_halfcheetah_kernel_stats_device.csv"))))
     assert any("rollout_kernel<2, hipets::KSpec<1, 13, 3, 2, 1, 4, 0, 0, 0, 1>" in x["Name"] for x in rows)
 
 
@@ -137,10 +139,10 @@ def test_pmc_summary_counts_the_kernel_this_repository_ships():
     particles).  A counter file from another kernel or another workload would not reproduce these integers."""
     per_tile_step = 13 * 6 + 3 * 13 * 50 + 3 * 50
     assert per_tile_step == 2178
-    for tag in ("r2", "r3", "r4", "r5"):  # round 3's fused output layer issues the same MFMAs (another pack of the same 3 column tiles)
+    for tag in ("r2", "r3", "r4", "r5", "r6"):  # round 3's fused output layer issues the same MFMAs (another pack of the same 3 column tiles)
         pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_rollout_pmc.json")))
         # round 5: FAST rows are dealt as one run -- ceil(625 row tiles / 3) = 209 workgroups instead of 11 x 20
-        fast_wgs = 209 if tag == "r5" else 11 * 20
+        fast_wgs = 209 if tag in ("r5", "r6") else 11 * 20
         assert pmc["device"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (5 * 42 * 3) * 30, tag
         assert pmc["fast"]["per_launch_avg"]["SQ_INSTS_MFMA"] == per_tile_step * (fast_wgs * 3) * 30, tag
         for mode in ("device", "fast"):
@@ -188,3 +190,43 @@ def test_round5_blocks_model_env_step_planet_and_instances_per_population_size()
         assert sorted(map(int, inst), reverse=True) == [1036, 805, 630, 497, 358]
         assert all(v == ["wide", 2] for v in inst.values())
     assert icem["fast"]["roofline"]["frac"] > 0.43  # the round-4 verdict's plan-level target for FAST mode
+
+
+def test_round6_the_headline_is_the_library_default_and_the_carried_items_moved():
+    """Round 6: (1) the headline objective is built WITHOUT a mode argument -- it measures what `hipets.make_eval_fn(model, P)` gives a user,
+    the reference's TS1 semantics; (2) the CPU baseline names the port / reference calibration and the line prints the reference-
+    equivalent ratio beside GPU / port; (3) `hipets_step` in FAST mode no longer pays a schedule kernel (0.441 -> <= 0.35 ms per 100 000-row
+    call, within 2 % of DEVICE mode's rate); (4) cfg4' (Humanoid-v4) in DEVICE mode: the LDS-DMA collect and the by-column input pass."""
+    d = _line()
+    assert d["config"]["mode_is_the_library_default"] is True and d["config"]["mode"].startswith("DEVICE")
+    c = d["cpu_baseline"]
+    if c["kind"] == "port":
+        assert 0.5 < c["port_over_reference"] < 1.2 and c["calibration"]["file"].startswith("profiles/")
+        assert d["config"]["gpu_over_cpu_reference_equivalent"] == pytest.approx(d["config"]["gpu_over_cpu"] * c["port_over_reference"], rel=1e-9)
+    st = d["model_env_step"]
+    assert st["fast"]["ms_per_call"] <= 0.35 and st["fast"]["value"] >= 0.98 * st["device"]["value"]
+    assert st["fast"]["roofline"]["launches_per_call"] == 1.0
+    icem = d["other_configs"]["configs[3] cfg4' iCEM Humanoid-v4 (obs 376)"]
+    assert icem["device"]["roofline"]["frac"] > 0.385 and icem["device"]["ms_per_plan"] < 31.5  # round 5: 0.366, 33.0 ms
+    it = json.load(open(os.path.join(ROOT, "profiles", "r6_cfg4p_iterations.json")))
+    shipped, before = it["shipped (closing session)"], it["r6c: -DHIPETS_DMA_COLLECT=0 (the round-5 register path), same box"]
+    assert shipped["1036"]["device"]["frac"] >= 0.40 and shipped["sum_ms"]["device"] < 0.95 * before["sum_ms"]["device"]
+
+
+def test_round6_phase_profile_is_of_the_shipped_one_tile_instances():
+    """profiles/r6_one_tile_phase_profile.json comes from a -DHIPETS_LEAN_PROF=1 build: the FUSED one-tile instances stamped (rounds 2-5
+    committed the generic kernel's phases under this heading), every phase carries its mark count, and wave 3's barrier time reflects the
+    k-split (round 5's generic-kernel profile read 11 k cycles per step; a wave that holds a quarter of the 13th tile waits ~5 k)."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r6_one_tile_phase_profile.json")))
+    assert "leanprof" in d["lib"]
+    cfg1 = next(v for k, v in d.items() if k.startswith("cfg1"))
+    for mode in ("device", "fast"):
+        r = cfg1[mode]
+        assert r["kernel_class"] == ["fused", 1] and r["instance_stamped"] is True
+        assert 50 < r["cycles_per_mark_calibrated"] < 250
+        w0, w3 = r["wave0"], r["wave3"]
+        assert w0["marks_per_step"]["k loop"] >= 5 and w0["cycles_per_step_corrected"]["k-split share"] > 1000
+        assert w3["cycles_per_step_corrected"]["layer barrier"] < 8000
+        assert w0["total_corrected"] == pytest.approx(r["us_per_step_unprofiled"] * r["clock_ghz_implied"] * 1e3, rel=0.08)
+    pl = next(v for k, v in d.items() if k.startswith("planet"))
+    assert pl["instance_stamped"] is True and pl["wave0"]["cycles_per_step_corrected"]["k loop"] > 40000
