@@ -302,3 +302,32 @@ def test_timed_out_persistent_rollout_is_reported_and_the_plan_is_rerun(engine):
         engine.set_persistent(True)
     ok = engine.rollout(actions, s0, P, mode="device", seed=7, stream_id=1)  # the persistent form works again afterwards
     assert torch.equal(ok, ref_rollout) and not engine.check_async_error()
+
+
+def test_timed_out_lds_dma_collect_of_the_wide_instance_is_reported(engine):
+    """The WIDE instances (Humanoid-v4's 376-dim state) collect a turn's rows by LDS-DMA (rollout.hpp dma_collect, round 6): a chunk with a
+    stale lane is fetched again until the poll bound.  With a zero bound the first miss gives up: the flag must trip (a step's first turn
+    always finds some row unpublished at this size), nothing may hang or fault (no DMA may still be landing in the activation buffers when
+    the flow goes on), and the per-step launches the engine falls back to return what an engine that never used the persistent form does."""
+    obs, act, pop, P, H = 376, 17, 660, 20, 3
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, ensemble_size=5, hid=200, termination="humanoid")
+    engine.set_model(to_spec(om, obs, act))
+    assert engine.kernel_class(pop, P, H, "device") == ("wide", 2)
+    a = actions.to(DEV)
+    try:
+        engine.set_persistent(False)
+        ref = engine.rollout(a, s0, P, mode="device", seed=7, stream_id=1).clone()
+        engine.set_persistent(True)
+        ok = engine.rollout(a, s0, P, mode="device", seed=7, stream_id=1)
+        assert torch.equal(ok, ref) and not engine.check_async_error()
+        engine.set_handover_timeout(0.0)
+        bad = engine.rollout(a, s0, P, mode="device", seed=7, stream_id=1)
+        torch.cuda.synchronize()
+        assert engine.check_async_error(), "a zero poll bound did not trip: the test does not exercise dma_collect's give-up path"
+        del bad
+        again = engine.rollout(a, s0, P, mode="device", seed=7, stream_id=1)  # per-step launches now
+        assert torch.equal(again, ref)
+    finally:
+        engine.set_handover_timeout(0.2)
+        engine.set_persistent(True)
+    assert torch.equal(engine.rollout(a, s0, P, mode="device", seed=7, stream_id=1), ref) and not engine.check_async_error()
