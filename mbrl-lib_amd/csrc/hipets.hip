@@ -878,6 +878,10 @@ int rollout_impl(hipets_engine* e, const float* actions, const float* s0, int32_
             ra.t_begin = 0;
             ra.t_end = H;
             ra.n_logical = domains * groups;
+            // KSpec::WIDE two-tile instances deal a ragged last turn in one-tile logical workgroups (rollout.hpp "Ragged last turn": same
+            // bits, 0.69 of the turn's time); HIPETS_RAGGED_LAST_TURN=0 keeps two-tile turns throughout (A/B measurements)
+            static const bool ragged_ok = [] { const char* v = std::getenv("HIPETS_RAGGED_LAST_TURN"); return !(v && v[0] == '0'); }();
+            ra.ragged_last_turn = (wide && R == 2 && ragged_ok) ? 1 : 0;
 
             if (launch_rollout(e, R, domains * groups, lds, ra, st)) return 1;  // cut to the resident capacity by the launcher
         } else if (per_step) {

@@ -127,6 +127,9 @@ struct RolloutArgs {
     int* capacity_out;             // HOST pointer, launcher only: when set, no launch -- the resident capacity (workgroups) is stored here
     int n_logical;                 // persistent form: logical workgroups (member domain x row group); a launched workgroup serves the
                                    // logical ones wg, wg + gridDim.x, ... one after the other within every step (batches larger than the chip)
+    int ragged_last_turn;          // persistent form, KSpec::WIDE two-tile instances: when the row tiles the LAST turn of a step would serve
+                                   // fit one per launched workgroup, that turn is dealt in ONE-tile logical workgroups (rollout_kernel:
+                                   // "ragged last turn"); 0 = always two-tile turns (A/B measurements: HIPETS_RAGGED_LAST_TURN=0)
     const PermKeys* step_keys;     // DEVICE [H]: round keys of every step's permutation
     int* error_flag;               // HOST-mapped: set to 1 when a poll exceeds its bound (another workgroup was not resident); once it is
                                    // set every later poll of the launch gives up after <= 64 spins, so a stranded grid drains in
@@ -1814,6 +1817,49 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                         : fast_member((unsigned)wg, gridDim.x, ra.fm_a, ra.fm_b, md.M, md.iid_members, ra.seed, ra.stream_id,
                                       md.propagation == HIPETS_PROP_FIXED_MODEL ? 0xFFFFFFFFu : (unsigned)ra.t_begin));
     const bool persist = !fast && ra.exchange != nullptr;  // DEVICE mode in ONE launch: rows are handed over through `exchange`
+    // ---- Ragged last turn (round 6; KSpec::WIDE two-tile instances in the turn-based persistent form) -------------------------------
+    // A batch of n2 two-tile logical workgroups on G launched ones is served in ceil(n2 / G) turns per step, and a step is as long as
+    // its turns: the last turn costs a whole two-tile turn however few rows it holds (cfg4' iCEM, 497 candidates: 315 logical
+    // workgroups = 256 + 59 -- the second turn is 23 % full and the rollout takes exactly as long as the 805-candidate one).  When
+    // the row tiles left for the last turn fit ONE per launched workgroup, that turn is dealt in one-tile logical workgroups instead
+    // -- v >= half_from: (member domain, tile) in domain-major order behind the last full turn -- and runs the R = 1 bodies of the
+    // MLP ops on row tile 0 of the same LDS layout (the turn costs 0.69 of a two-tile one).  Which workgroup holds a row never
+    // enters the arithmetic (the step's permutation decides the member, every (column tile, row tile) unit sums in the same k
+    // order whatever R is): same bits as the two-tile dealing, the per-step launches and the generic kernel (tested).
+    constexpr bool kRagged = S::WIDE && R == 2;
+    int half_from = 0x7FFFFFFF;     // first one-tile logical workgroup
+    int n_logical = ra.n_logical;   // logical workgroups of this launch
+    int hf_dom = 0, hf_tile = 0, hf_tpd = 1;  // where the one-tile range starts (member domain, tile in it); tiles per domain
+    if constexpr (kRagged) {
+        if (persist && ra.ragged_last_turn) {
+            const int G = (int)gridDim.x, n2 = ra.n_logical;
+            const int turns2 = (n2 + G - 1) / G, full = (turns2 - 1) * G;  // two-tile logical workgroups of the full turns
+            if (turns2 >= 2) {
+                hf_tpd = (ra.rows_per_domain + kTile - 1) / kTile;
+                hf_dom = full / ra.groups;
+                hf_tile = 2 * (full - hf_dom * ra.groups);
+                const int rem = (hf_tpd - hf_tile) + (n2 / ra.groups - 1 - hf_dom) * hf_tpd;  // row tiles behind the full turns
+                if (rem <= G) {
+                    half_from = full;
+                    n_logical = full + rem;
+                }
+            }
+        }
+    }
+    // logical workgroup v -> its member domain, first row slot in the domain, rows it holds
+    auto logical_rows = [&](const int v, int& dom, int& j0, int& live) __attribute__((always_inline)) {
+        if (!kRagged || v < half_from) {
+            dom = v / ra.groups;
+            j0 = (v - dom * ra.groups) * ROWS;
+            live = ROWS;
+        } else {
+            int w = v - half_from + hf_tile;  // tile index counted from the start of domain hf_dom
+            const int dd = w / hf_tpd;
+            dom = hf_dom + dd;
+            j0 = (w - dd * hf_tpd) * kTile;
+            live = kTile;
+        }
+    };
     const bool poll_every = ra.poll_ticks < 1000;  // bounds below 10 us (tests of the time-out path): look at the clock on every spin, not every 64th
     // hand-over table row = NVP pairs of 8-byte granules: the state dims (padded to an even count), then {running total, flag}.
     // exchange item i = (row slot i / NVP, pair i % NVP): items tid + q * kThreads of a thread are the same every step
@@ -2130,6 +2176,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
 #ifndef HIPETS_INPUT_BY_COLUMN
 #define HIPETS_INPUT_BY_COLUMN 1
 #endif
+    int in_rows = ROWS;  // rows of the input image the next MLP pass reads (kTile in a one-tile turn: "ragged last turn" above)
     auto build_input_cols = [&](const int t, float* const dst) __attribute__((always_inline)) {
         const float* actn_t = sm.actn + (t & 1) * n_act;
         constexpr int kU = 8;  // rows per batch: the batch's LDS reads are issued together
@@ -2142,7 +2189,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             const float* const src = from_state ? sm.state + cc : actn_t + (cc - md.obs_in);
             const int stride = from_state ? md.obs_dim : md.act_dim;
             float* const out = dst + lds_col(c);
-            for (int s0_ = 0; s0_ < ROWS; s0_ += kU) {
+            for (int s0_ = 0; s0_ < in_rows; s0_ += kU) {  // (a one-tile turn of the ragged last turn: row tile 0 only)
                 float x[kU];
                 int rid[kU];
 #pragma unroll
@@ -2252,7 +2299,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     // logical workgroups in turn (sequence index q = step * n_serve + turn); each turn collects its rows from the hand-over
     // table, runs the step, publishes.  Only a step's first turn can find rows missing (published by other workgroups' last
     // turns of the previous step); the later turns' rows arrived while the earlier ones computed.
-    const int n_serve = persist ? (ra.n_logical - wg + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int n_serve = persist ? (n_logical - wg + (int)gridDim.x - 1) / (int)gridDim.x : 1;
     const int n_seq = (ra.t_end - ra.t_begin) * n_serve;
     int stamp_seq = 0;  // (profiling builds: index of the current (step, turn) for HIPETS_STAMP)
     (void)stamp_seq;
@@ -2447,6 +2494,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
     };
     (void)dma_collect;
 
+    bool one_tile = false;  // this turn serves a one-tile logical workgroup (kRagged; workgroup-uniform)
     for (int q_seq = 0; q_seq < n_seq; ++q_seq) {
         stamp_seq = q_seq;
         const int t = ra.t_begin + q_seq / n_serve;
@@ -2490,7 +2538,12 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     fetch_actions_issue(t + 1, av);
                 }
                 if (l == L - 2 && (write_input || prep_next || wide_fast_next)) fetch_actions_commit(t + 1, av);
-                mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof, sm.part);
+                if constexpr (kRagged) {
+                    if (one_tile) mlp_layer<1, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof, sm.part);
+                    else mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof, sm.part);
+                } else {
+                    mlp_layer<R, S>(md, sm.lmeta, l, member, cur, nxt, wave, lane, prof, sm.part);
+                }
                 __syncthreads();
                 prof.mark(8);
                 float* tmp = cur; cur = nxt; nxt = tmp;
@@ -2653,7 +2706,12 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             auto tail_finish = [&]() __attribute__((always_inline)) {};
             const auto tail = make_tail(tail_prep, tail_unit, tail_finish);
             prof.mark(12);
-            mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
+            if constexpr (kRagged) {
+                if (one_tile) mlp_output_layer_fused<1, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
+                else mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
+            } else {
+                mlp_output_layer_fused<R, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
+            }
             // straight persistent form: what the two sides of this barrier exchange goes through LDS; the tail's write-through
             // hand-over stores need not have been acknowledged (__syncthreads() would wait for that -- about a microsecond --
             // before the first poll for the incoming rows is even issued; this way the two round trips overlap)
@@ -2676,10 +2734,16 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 continue;
             }
             if (persist && has_next) {  // the slot's row in the next turn (the tail above was the last reader of this turn's rowid)
+                int nd, nj0, nlive;
+                logical_rows(v_next, nd, nj0, nlive);
+                if constexpr (kRagged) {
+                    one_tile = nlive < ROWS;
+                    in_rows = nlive;
+                }
                 for (int s = tid; s < ROWS; s += kThreads) {
-                    const int j = (v_next % ra.groups) * ROWS + s;
-                    sm.rowid[s] = j < ra.rows_per_domain
-                                      ? (int)perm_apply((unsigned)((v_next / ra.groups) * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
+                    const int j = nj0 + s;
+                    sm.rowid[s] = (s < nlive && j < ra.rows_per_domain)
+                                      ? (int)perm_apply((unsigned)(nd * ra.rows_per_domain + j), ra.perm_n, ra.perm_a, ra.perm_b, ra.step_keys[t_next]) : -1;
                     sm.lrew[s] = 0.f;
                 }
                 __syncthreads();
@@ -2885,7 +2949,10 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
         HIPETS_STAMP(1, t);  // sampled, rewarded, published
         if (persist && has_next) {
             // ---- collect the rows of the next turn: 8-byte {value bits, step tag} granules, self-validating ----
-            domain = v_next / ra.groups;
+            {
+                int nj0, nlive;
+                logical_rows(v_next, domain, nj0, nlive);
+            }
             member_dom = domain;
             compute_act_base();
             float av2[kPrefetch];

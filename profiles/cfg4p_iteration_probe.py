@@ -23,7 +23,7 @@ P, H = 20, 40
 s0 = np.zeros(obs, np.float32)
 s0[0] = 1.4
 out = {"obs": obs, "lib": os.environ.get("HIPETS_LIB", "default")}
-for pop in (1036, 805, 630, 497, 358):
+for pop in [int(x) for x in os.environ.get("PROBE_POPS", "1036,805,630,497,358").split(",")]:
     acts = (torch.rand(pop, H, 17) * 2 - 1).to(dev)
     rec = {}
     for mode in ("fast", "device"):
@@ -31,7 +31,7 @@ for pop in (1036, 805, 630, 497, 358):
             rec[f"{mode}_class"] = list(eng.kernel_class(pop, P, H, mode=mode))
         except Exception as exc:  # noqa: BLE001
             rec[f"{mode}_class"] = str(exc)
-        for R in (0, 1, 2, 3, 4):
+        for R in [int(x) for x in os.environ.get("PROBE_RS", "0,1,2,3,4").split(",")]:
             f = lambda i=0: eng.rollout(acts, s0, P, mode=mode, seed=1, stream_id=i, rows_per_group=R)  # noqa: E731
             try:
                 t0 = time.perf_counter()

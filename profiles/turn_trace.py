@@ -17,10 +17,13 @@ import hipets  # noqa: E402
 dev = torch.device("cuda:0")
 eng = hipets.get_engine(dev)
 out = {"lib": hipets.LIB_PATH}
-for name, obs, R, serve in (("cfg4p_obs376", 376, 2, 3), ("cfg4_obs45", 45, 3, 2)):
+CASES = (("cfg4p_obs376", 376, 2, 3, 1036), ("cfg4_obs45", 45, 3, 2, 1036))
+if os.environ.get("TRACE_CASES"):  # "name:obs:R:turns:pop,..." -- e.g. the ragged last turn of cfg4''s fourth iCEM iteration: cfg4p_pop497:376:2:2:497
+    CASES = tuple((c.split(":")[0], *[int(x) for x in c.split(":")[1:]]) for c in os.environ["TRACE_CASES"].split(","))
+for name, obs, R, serve, pop in CASES:
     spec = bench.synthetic_spec(dev, obs=obs, act=17, ensemble=7, elite=[0, 1, 2, 3, 4], termination="humanoid")
     eng.set_model(spec)
-    pop, P, H = 1036, 20, 40
+    P, H = 20, 40
     acts = (torch.rand(pop, H, 17, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
     s0 = np.zeros(obs, np.float32)
     s0[0] = 1.4

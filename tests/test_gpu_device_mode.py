@@ -189,6 +189,52 @@ def test_every_shipped_device_instance_persistent_equals_per_step(engine, name, 
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def ragged_last_turn(pop, P, M, grid=256):
+    """rollout.hpp 'Ragged last turn', restated: (turns, row tiles behind the full two-tile turns, dealt one per workgroup?)"""
+    tpd = -(-(pop * P // M) // 16)
+    groups = -(-tpd // 2)
+    n2 = M * groups
+    turns = -(-n2 // grid)
+    if turns < 2:
+        return turns, 0, False
+    full = (turns - 1) * grid
+    d0, p0 = divmod(full, groups)
+    rem = (tpd - 2 * p0) + (M - 1 - d0) * tpd
+    return turns, rem, rem <= grid
+
+
+# (population, (turns, row tiles behind the full turns, ragged?)) on 256 CUs with 5 elite members x 20 particles
+RAGGED = [(497, (2, 117, True)),    # cfg4' iCEM, fourth iteration: the one-tile range starts inside the last member's domain
+          (505, (2, 127, True)),    # ... exactly on a member boundary
+          (520, (2, 138, True)),    # ... inside member 3 and runs on through member 4
+          (609, (2, 256, True)),    # one tile for every launched workgroup: the limit
+          (613, (2, 258, False)),   # two tiles too many: two-tile turns throughout
+          (1001, (3, 235, True)),   # two full turns first
+          (1017, (3, 255, True))]
+
+
+@pytest.mark.parametrize("pop,expect", RAGGED, ids=[f"pop{p}" for p, _ in RAGGED])
+def test_ragged_last_turn_of_the_wide_instance_equals_per_step_launches(engine, pop, expect):
+    """Round 6: the WIDE two-tile instance deals the LAST turn of a step in one-tile logical workgroups when the row tiles left for it
+    fit one per launched workgroup, and runs the R = 1 bodies of the MLP ops for that turn (rollout.hpp 'Ragged last turn').  Which
+    workgroup holds a row never enters the arithmetic: one persistent launch must equal H per-step launches (whose geometry knows no
+    turns) bit for bit -- at sizes on both sides of the limit, with the one-tile range starting inside a member domain and on a
+    member boundary."""
+    obs, act, P, H, M = 376, 17, 20, 3, 5
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert ragged_last_turn(pop, P, M) == expect
+    om, actions, s0, _, _ = _random_case(obs, act, pop, P, H, ensemble_size=7, hid=200, elite=list(range(M)), termination="humanoid")
+    engine.set_model(to_spec(om, obs, act))
+    assert engine.kernel_class(pop, P, H, "device") == ("wide", 2)
+    a = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=5, stream_id=3)
+    engine.set_persistent(False)
+    try:
+        b = engine.rollout(actions.to(DEV), s0, P, mode="device", seed=5, stream_id=3)
+    finally:
+        engine.set_persistent(True)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_error_behaviour_of_the_round2_entry_points(engine):
     """Plan mode / trace / batched-plan misuse fails with a message, never silently: non-zero C return -> HipetsError."""
     from hipets.planning import _BoundObjective
