@@ -4,6 +4,8 @@
 // optimize (mbrl/planning/trajectory_opt.py:110-188) and mbrl.util.math.truncated_normal_
 // (mbrl/util/math.py:69-92, a host-synchronising rejection loop in the reference).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace hipets {
@@ -77,7 +79,7 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
     population[i] = x;
 }
 
-// NaN filter + top-k + refit + best-so-far in ONE workgroup (pop <= kMaxPop): the K best values are found in LDS
+// NaN filter + top-k + refit + best-so-far, the selection in ONE workgroup (pop <= kMaxPop): the K best values are found in LDS
 // (descending, ties broken by lower index: rank counting for small populations, a radix select + a sort of the elites for
 // larger ones, a full bitonic network when K > kSelectMaxK), then threads share the dimensions d of the [H,A] plan and
 // reduce the K elites in f64.
@@ -93,14 +95,21 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
                                                                  float* disp, float* best_value, float* best_solution,
                                                                  int* elite_idx_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    {  // one workgroup per environment: rebase every pointer to this environment's slice
-        const int env = blockIdx.x;
+    {  // gridDim.y environments (gridDim.x workgroups each): rebase every pointer to this environment's slice
+        const int env = blockIdx.y;
         values += (size_t)env * p.pop;
         if (p.totals) {
             const float* tot = p.totals + (size_t)env * p.pop * p.P;
             for (int i = threadIdx.x; i < p.pop; i += kRefitThreads) {
-                float s = 0.f;
-                for (int q = 0; q < p.P; ++q) s += tot[(size_t)i * p.P + q];
+                float s = 0.f;  // the same sequential sum; a candidate's particle totals fetched eight at a time
+                for (int q0 = 0; q0 < p.P; q0 += 8) {
+                    float tv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) tv[u] = tot[(size_t)i * p.P + min(q0 + u, p.P - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (q0 + u < p.P) s += tv[u];
+                }
                 values[i] = s / (float)p.P;
             }
         }
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         best_solution += (size_t)env * p.D;
         if (elite_idx_out) elite_idx_out += (size_t)env * p.K;
     }
-    const int* const elite_in = p.elite_in ? p.elite_in + (size_t)blockIdx.x * p.K : nullptr;
+    const int* const elite_in = p.elite_in ? p.elite_in + (size_t)blockIdx.y * p.K : nullptr;
     int n2 = 1;
     while (n2 < p.pop) n2 <<= 1;
     float* key = reinterpret_cast<float*>(smem);
@@ -260,28 +269,51 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
             __syncthreads();
         }
     }
-    if (elite_idx_out)
+    if (elite_idx_out && blockIdx.x == 0)
         for (int k = tid; k < p.K; k += kRefitThreads) elite_idx_out[k] = idx[k];
 
     // best-so-far (trajectory_opt.py:184-186)
     const float top = key[0];
-    const bool improved = top > best_value[0];
+    const bool improved = blockIdx.x == 0 && top > best_value[0];
     const int top_i = idx[0];
     __syncthreads();
 
-    // elite mean / variance: `parts` threads share a dimension (each owns every parts-th elite, independent loads in
-    // flight), partial sums meet in LDS; consecutive threads own consecutive dimensions (coalesced rows).  f64 throughout.
+    // elite mean / variance: `parts` threads share a dimension (each owns every parts-th elite), partial sums meet in LDS; consecutive
+    // threads own consecutive dimensions (coalesced rows).  f64 throughout.  Round 6: the D dimensions of the plan are dealt to the
+    // gridDim.x workgroups of the environment (each repeats the selection above -- same inputs, same result -- and refits its own slice;
+    // workgroup 0 also keeps the best-so-far), so that a slice is at most 128 dimensions wide and eight threads share each: a thread's
+    // share of the K elites (cfg2: 7 of 50, cfg4: 13 of 103) is fetched in ONE round trip and held in registers for the variance pass
+    // (the single-workgroup version walked a 103-load chain twice per thread for cfg4's 680 dimensions: 20 of its 48 us).
     double* red = reinterpret_cast<double*>(smem + (size_t)n2 * 8);  // [kRefitThreads]
-    int parts = kRefitThreads / p.D;
+    const int nb = (int)gridDim.x, bx = (int)blockIdx.x;
+    const int Dslice = (((p.D + nb - 1) / nb + 63) / 64) * 64;  // dimensions per workgroup (a multiple of the wave width)
+    const int d_lo = bx * Dslice, d_hi = min(p.D, d_lo + Dslice);
+    int parts = kRefitThreads / Dslice;
     parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
     const int G = kRefitThreads / parts;  // dimensions per sweep
     const int part = tid / G, dloc = tid % G;
-    for (int base = 0; base < p.D; base += G) {
+    const int nu = (p.K + parts - 1) / parts;  // elites per thread (workgroup-uniform)
+    // One sweep of G dimensions with NU >= nu elites per thread held in registers (HOLD), or walked NU at a time and fetched again for the
+    // variance (more than 16 per thread: K > 128).  Every load of a batch is unconditional, its indices clamped: a guarded load is a
+    // branch per element, and the merge behind it waits for the load -- the round trips would go out one after the other.
+    auto sweep = [&](const int base, auto nu_tag, auto hold_tag) __attribute__((always_inline)) {
+        constexpr int NU = decltype(nu_tag)::value;
+        constexpr bool HOLD = decltype(hold_tag)::value;
         const int d = base + dloc;
-        const bool live = d < p.D && part < parts;
+        const bool live = d < d_hi && part < parts;
+        float mu_old = 0.f, disp_old = 0.f;
+        float xv[NU];
         double s = 0.0;
-        if (live)
-            for (int k = part; k < p.K; k += parts) s += (double)population[(size_t)idx[k] * p.D + d];
+        if (live) {
+            if (part == 0) { mu_old = mu[d]; disp_old = disp[d]; }  // (in flight beside the elites' rows)
+            for (int k0 = part; k0 < (HOLD ? part + 1 : p.K); k0 += parts * NU) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) xv[u] = population[(size_t)idx[min(k0 + u * parts, p.K - 1)] * p.D + d];
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (k0 + u * parts < p.K) s += (double)xv[u];
+            }
+        }
         red[tid] = s;
         __syncthreads();
         double mean = 0.0;
@@ -291,11 +323,20 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         }
         __syncthreads();
         double ss = 0.0;
-        if (live)
-            for (int k = part; k < p.K; k += parts) {
-                const double dv = (double)population[(size_t)idx[k] * p.D + d] - mean;
-                ss += dv * dv;
+        if (live) {
+            for (int k0 = part; k0 < (HOLD ? part + 1 : p.K); k0 += parts * NU) {
+                if constexpr (!HOLD) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) xv[u] = population[(size_t)idx[min(k0 + u * parts, p.K - 1)] * p.D + d];
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (k0 + u * parts < p.K) {
+                        const double dv = (double)xv[u] - mean;
+                        ss += dv * dv;
+                    }
             }
+        }
         red[tid] = ss;
         __syncthreads();
         if (live && part == 0) {
@@ -304,14 +345,43 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
             var /= (double)(p.unbiased ? (p.K - 1) : p.K);
             const float new_mu = (float)mean;
             const float new_disp = p.clipped ? (float)sqrt(var) : (float)var;  // :134-137
-            mu[d] = p.alpha * mu[d] + p.one_minus_alpha * new_mu;               // :138
-            disp[d] = p.alpha * disp[d] + p.one_minus_alpha * new_disp;         // :139
-            if (improved) best_solution[d] = population[(size_t)top_i * p.D + d];
+            mu[d] = p.alpha * mu_old + p.one_minus_alpha * new_mu;              // :138
+            disp[d] = p.alpha * disp_old + p.one_minus_alpha * new_disp;        // :139
         }
         __syncthreads();
+    };
+    // the new best plan (workgroup 0, every dimension of it): its row is requested now, beside the elites' rows, and stored behind the sweeps
+    constexpr int kBestHold = 4;
+    float best_row[kBestHold];
+    const bool best_held = p.D <= kBestHold * kRefitThreads;
+    if (improved && best_held) {
+#pragma unroll
+        for (int u = 0; u < kBestHold; ++u) best_row[u] = population[(size_t)top_i * p.D + min(tid + u * kRefitThreads, p.D - 1)];
     }
-    if (improved && tid == 0) best_value[0] = top;
+    for (int base = d_lo; base < d_hi; base += G) {
+        using T = std::true_type;
+        using F = std::false_type;
+        if (nu <= 2) sweep(base, std::integral_constant<int, 2>{}, T{});
+        else if (nu <= 4) sweep(base, std::integral_constant<int, 4>{}, T{});
+        else if (nu <= 8) sweep(base, std::integral_constant<int, 8>{}, T{});
+        else if (nu <= 16) sweep(base, std::integral_constant<int, 16>{}, T{});
+        else sweep(base, std::integral_constant<int, 16>{}, F{});
+    }
+    // best-so-far (:184-186): workgroup 0 alone reads and writes it (a workgroup that started late must not see the new value)
+    if (improved) {  // (workgroup 0 only: see `improved`)
+        if (best_held) {
+#pragma unroll
+            for (int u = 0; u < kBestHold; ++u)
+                if (tid + u * kRefitThreads < p.D) best_solution[tid + u * kRefitThreads] = best_row[u];
+        } else {
+            for (int d = tid; d < p.D; d += kRefitThreads) best_solution[d] = population[(size_t)top_i * p.D + d];
+        }
+        if (tid == 0) best_value[0] = top;
+    }
 }
+
+// workgroups per environment of a refit launch (the dimensions of the plan in slices of at most 128)
+inline int refit_blocks(const int D) { return D <= 128 ? 1 : (D + 127) / 128 > 8 ? 8 : (D + 127) / 128; }
 
 // trajectory_opt.py:103-108: dispersion0 = ones (clipped) or ((ub - lb)^2) / 16; mu0 = x0
 __global__ void cem_init_kernel(const CemDev p, const float* x0, const float* lower, const float* upper, float* mu,

@@ -1218,7 +1218,7 @@ int hipets_cem_refit(hipets_engine* e, const hipets_cem_params* p, float* values
     const CemDev c = make_cem(p);
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, elite_idx);
     HCHECK(hipGetLastError());
     return 0;
@@ -1234,7 +1234,7 @@ int hipets_cem_refit_elites(hipets_engine* e, const hipets_cem_params* p, float*
     c.elite_in = elites;
     int n2 = 1;
     while (n2 < c.pop) n2 <<= 1;
-    hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, reinterpret_cast<hipStream_t>(stream), c,
                        values, population, mu, dispersion, best_value, best_solution, (int*)nullptr);
     HCHECK(hipGetLastError());
     return 0;
@@ -1270,7 +1270,7 @@ int hipets_mppi_update(hipets_engine* e, int32_t pop, int32_t H, int32_t A, doub
     if (!e || !values || !population || !mean) return fail("null argument");
     if (pop < 1 || pop > 12000 || H < 1 || A < 1) return fail("population_size %d outside [1, 12000]", pop);
     HCHECK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(mppi_update_kernel, dim3(1), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4,
+    hipLaunchKernelGGL(mppi_update_kernel, dim3(mppi_update_blocks(H * A), 1), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4,
                        reinterpret_cast<hipStream_t>(stream), pop, H * A, (float)gamma, values, population, mean);
     HCHECK(hipGetLastError());
     return 0;
@@ -1283,10 +1283,8 @@ int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t H, int32_t A, double
     if (n < 1 || A < 1) return fail("bad n/act_dim");
     if (H < 2 || H > kMaxHorizon) return fail("iCEM horizon %d outside [2, %d]", H, kMaxHorizon);
     HCHECK(hipSetDevice(e->device));
-    const int total = n * A;
-    hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), 1, n, n, H, A,
-                       (float)exponent, mu, var, lower, upper, normals, (unsigned long long)seed, (unsigned long long)stream_id,
-                       population);
+    launch_icem_sample(reinterpret_cast<hipStream_t>(stream), 1, n, n, H, A, (float)exponent, mu, var, lower, upper, normals, (unsigned long long)seed,
+                       (unsigned long long)stream_id, population);
     HCHECK(hipGetLastError());
     return 0;
 }
@@ -1349,7 +1347,7 @@ int hipets_plan_cem_batched(hipets_engine* e, const hipets_cem_params* p, int32_
         CemDev cr = c;
         cr.totals = e->totals.as<float>();
         cr.P = P;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, cr, e->values.as<float>(),
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(cr.D), n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, cr, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
@@ -1429,7 +1427,7 @@ int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t 
             return 0;
         };
         auto update = [&]() -> int {
-            hipLaunchKernelGGL(mppi_update_kernel, dim3(n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
+            hipLaunchKernelGGL(mppi_update_kernel, dim3(mppi_update_blocks((int)nd), n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
                                e->values.as<float>(), e->population.as<float>(), mean);
             HCHECK(hipGetLastError());
             return trace_iter(e, k, (int)npop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st, n_env);
@@ -1540,10 +1538,8 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
         const int n = sizes[i], rows = rows_of[i], extra = rows - n;
         const uint64_t sid = (plan_id * (uint64_t)iters + (uint64_t)i) * 4;
         auto sample = [&]() -> int {  // identical on every rank of a sharded plan: same seed, same counters
-            const int total = n_env * n * A;
-            hipLaunchKernelGGL(icem_sample_kernel, dim3((total + 127) / 128), dim3(128), 0, st, n_env, rows, n, H, A, (float)p->colored_noise_exponent,
-                               e->mu.as<float>(), e->disp.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed,
-                               (unsigned long long)sid, popbuf);
+            launch_icem_sample(st, n_env, rows, n, H, A, (float)p->colored_noise_exponent, e->mu.as<float>(), e->disp.as<float>(), lower, upper,
+                               (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid, popbuf);
             HCHECK(hipGetLastError());
             if (!extra) return 0;
             float* tail = popbuf + (size_t)n * nd;  // environment 0's extra rows; the others follow rows * nd floats apart
@@ -1580,7 +1576,7 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
             if (check_cem(&cp)) return 1;
             int n2 = 1;
             while (n2 < rows) n2 <<= 1;
-            hipLaunchKernelGGL(cem_refit_kernel, dim3(n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
+            hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks((int)nd), n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
                                e->values.as<float>(), popbuf, e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                                e->best_solution.as<float>(), e->elite_idx.as<int>());
             HCHECK(hipGetLastError());
@@ -1758,7 +1754,7 @@ int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const f
         po.stream_id = sid;
         if (hipets_planet_rollout(e, e->population.as<float>(), latent0, belief0, c.pop, c.H, P, &po, e->values.as<float>(), stream)) return 1;
         int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
@@ -1862,7 +1858,7 @@ int hipets_plan_cem_sharded(hipets_engine* e, const hipets_cem_params* p, const 
         };
         auto refit = [&]() -> int {
             int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
-            hipLaunchKernelGGL(cem_refit_kernel, dim3(1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+            hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
                                e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                                e->best_solution.as<float>(), eidx);
             HCHECK(hipGetLastError());

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int 
     float* w = reinterpret_cast<float*>(smem);                // [pop]
     float* red = w + pop;                                     // [kMppiThreads]
     const int tid = threadIdx.x;
-    {  // one workgroup per environment
-        const int env = blockIdx.x;
+    {  // gridDim.y environments
+        const int env = blockIdx.y;
         values += (size_t)env * pop;
         population += (size_t)env * pop * D;
         mean += (size_t)env * D;
@@ -82,26 +82,62 @@ __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int 
         __syncthreads();
     }
     const float norm = red[0] + 1e-10f;
-    for (int d = tid; d < D; d += kMppiThreads) {
+    // the weighted sum of a dimension is ONE f32 chain over the candidates (the order the reference's sum leaves is not defined; ours is
+    // fixed: c ascending).  Round 6: the chain's loads go out kChunk at a time (the first version waited for every load in turn: 146 us
+    // for pop 2 000 x 300 dimensions), and the dimensions are dealt to the gridDim.x workgroups of the environment, one wave each
+    // (every workgroup repeats the weights above: same inputs, same values).
+    constexpr int kChunk = 32;
+    for (int d = (int)blockIdx.x * 64 + tid; d < D && tid < 64; d += (int)gridDim.x * 64) {
         float acc = 0.f;
-        for (int c = 0; c < pop; ++c) acc += population[(size_t)c * D + d] * w[c];
+        float xa[kChunk], xb[kChunk];  // two batches: the next one is in flight while this one is summed
+        auto fetch = [&](float (&x)[kChunk], const int c0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u) x[u] = population[(size_t)min(c0 + u, pop - 1) * D + d];  // (unconditional: a guarded load is a branch)
+        };
+        auto sum = [&](const float (&x)[kChunk], const int c0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u)
+                if (c0 + u < pop) acc += x[u] * w[c0 + u];
+        };
+        fetch(xa, 0);
+        for (int c0 = 0; c0 < pop; c0 += 2 * kChunk) {
+            fetch(xb, c0 + kChunk);
+            sum(xa, c0);
+            fetch(xa, c0 + 2 * kChunk);
+            sum(xb, c0 + kChunk);
+        }
         mean[d] = acc / norm;
     }
 }
 
+// workgroups per environment of an MPPI update launch: one wave of dimensions each
+inline int mppi_update_blocks(const int D) { return D <= 64 ? 1 : ((D + 63) / 64 > 32 ? 32 : (D + 63) / 64); }
+
 // ---- iCEM ---------------------------------------------------------------------------------------------------
-// Coloured noise (util/math.py:318-396) + scale / clip (trajectory_opt.py:433-441).  One thread per
-// (candidate, action dim) draws the H/2+1 Fourier coefficients (unit normals scaled by f^(-exponent/2), DC and
-// Nyquist imaginary parts zero), inverts them with a direct real DFT (H <= 64 here: O(H^2) per series is a few
-// thousand FMAs) and normalises by the theoretical std so the series has unit variance.
+// Coloured noise (util/math.py:318-396) + scale / clip (trajectory_opt.py:433-441).  A thread of series (candidate, action dim)
+// draws the series' H/2+1 Fourier coefficients (unit normals scaled by f^(-exponent/2), DC and Nyquist imaginary parts zero),
+// inverts them with a direct real DFT for its share of the steps (H <= 128: O(H^2) per series is a few thousand FMAs) and
+// normalises by the theoretical std so the series has unit variance.
 constexpr int kMaxHorizon = 128;
-__global__ void icem_sample_kernel(int n_env, int row_stride, int n, int H, int A, float exponent, const float* __restrict__ mu,
-                                   const float* __restrict__ var, const float* __restrict__ lower, const float* __restrict__ upper,
-                                   const float* __restrict__ normals /* [2, n, A, H/2+1] or null */, unsigned long long seed,
-                                   unsigned long long stream, float* __restrict__ population) {
+// Round 6: the coefficients live in REGISTERS.  The first version kept re[] / im[] as run-time indexed local arrays, which the compiler
+// demotes to scratch memory (the only kernel of the library with scratch: 72 us per cfg4 iteration for 1 036 x 17 series of 40 steps).
+// Here the inverse transform's frequency loop is fully unrolled over NFMAX >= H / 2 + 1 (six instances: horizons up to 16 / 32 / 48 / 64 / 96 /
+// 128), branch-free.  A workgroup serves kSeries series with SPLIT threads each: the series' H / 2 + 1 coefficient pairs are drawn ONCE,
+// the draws dealt to its SPLIT threads, and parked in LDS columns; every thread then fetches all of them into registers (static
+// indices) and inverts its own share of the time steps.  Same draws, same arithmetic per element in the same order: same bits as the
+// first version (the plans' oracle replays and the reference goldens hold it).
+template <int NFMAX>
+__global__ __launch_bounds__((NFMAX > 33 ? 64 : 128) * 4) void icem_sample_kernel(int n_env, int row_stride, int n, int H, int A, float exponent,
+                                   const float* __restrict__ mu, const float* __restrict__ var, const float* __restrict__ lower,
+                                   const float* __restrict__ upper, const float* __restrict__ normals /* [2, n, A, H/2+1] or null */,
+                                   unsigned long long seed, unsigned long long stream, float* __restrict__ population) {
+    constexpr int kSeries = NFMAX > 33 ? 64 : 128;  // series per workgroup (the widest instance: 33 KB of coefficient columns)
     __shared__ float cs[kMaxHorizon], sn[kMaxHorizon], scale[kMaxHorizon / 2 + 1];
     __shared__ float sigma_s;
+    extern __shared__ float coef[];  // [2][NF][kSeries]
     const int NF = H / 2 + 1;
+    const int split = (int)blockDim.x / kSeries;  // threads per series
+    const int sl = (int)threadIdx.x % kSeries, q = (int)threadIdx.x / kSeries;
     for (int m = threadIdx.x; m < H; m += blockDim.x) {
         float s, c;
         sincosf(6.28318530717958647692f * (float)m / (float)H, &s, &c);
@@ -124,49 +160,94 @@ __global__ void icem_sample_kernel(int n_env, int row_stride, int n, int H, int 
         }
         sigma_s = 2.0f * sqrtf(acc) / (float)H;
     }
-    __syncthreads();
     // n_env environments sample n rows each into population [n_env][row_stride][H][A] from their own mu / var [n_env][H][A]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_env * n * A) return;
-    const int env = i / (n * A);
-    const int c = (i % (n * A)) / A, a = i % A;
+    const int i = blockIdx.x * kSeries + sl;  // the series: (environment, candidate, action dim)
+    const bool valid = i < n_env * n * A;
+    const int env = valid ? i / (n * A) : 0;
+    const int c = valid ? (i % (n * A)) / A : 0, a = valid ? i % A : 0;
     mu += (size_t)env * H * A;
     var += (size_t)env * H * A;
     population += (size_t)env * row_stride * H * A;
-    float re[kMaxHorizon / 2 + 1], im[kMaxHorizon / 2 + 1];
-    for (int f = 0; f < NF; ++f) {
-        float nr, ni;
-        if (normals) {
-            nr = normals[((size_t)c * A + a) * NF + f];
-            ni = normals[((size_t)n * A + (size_t)c * A + a) * NF + f];
-        } else {
-            const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)f, 0x1CE3u, (uint32_t)stream, (uint32_t)seed,
-                                            (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32));
-            box_muller(r.x, r.y, nr, ni);
+    const bool even = (H & 1) == 0;
+    // the draws of series i: frequency f by the thread with q = f % split (a real loop: unrolled, the compiler interleaves the Philox
+    // blocks and spills hundreds of registers)
+    if (valid) {
+#pragma nounroll
+        for (int f = q; f < NF; f += split) {
+            float nr, ni;
+            if (normals) {
+                nr = normals[((size_t)c * A + a) * NF + f];
+                ni = normals[((size_t)n * A + (size_t)c * A + a) * NF + f];
+            } else {
+                const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)f, 0x1CE3u, (uint32_t)stream, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32));
+                box_muller(r.x, r.y, nr, ni);
+            }
+            float vr = nr * scale[f], vi = ni * scale[f];
+            if (f == 0) vi = 0.f;                // :386
+            if (even && f == NF - 1) vi = 0.f;   // :382-383
+            coef[f * kSeries + sl] = vr;
+            coef[(NF + f) * kSeries + sl] = vi;
         }
-        re[f] = nr * scale[f];
-        im[f] = ni * scale[f];
     }
-    im[0] = 0.f;                       // :386
-    if ((H & 1) == 0) im[NF - 1] = 0.f;  // :382-383
+    __syncthreads();  // (also publishes sigma_s)
+    if (!valid) return;
+    float re[NFMAX], im[NFMAX];
+#pragma unroll
+    for (int f = 0; f < NFMAX; ++f) {
+        const int ff = f < NF ? f : NF - 1;  // (clamped: the select below drops what the copies contribute)
+        re[f] = coef[ff * kSeries + sl];
+        im[f] = coef[(NF + ff) * kSeries + sl];
+    }
+    const float re_last = coef[(NF - 1) * kSeries + sl];  // re[NF - 1]
     const float inv = 1.0f / ((float)H * sigma_s);
-    for (int t = 0; t < H; ++t) {  // irfft (backward norm 1/H), real output
+    const int fl = (H & 1) ? NF : NF - 1;  // frequencies with a distinct conjugate partner: 1 .. fl-1
+    // this thread's share of the time steps: [t0, t1) of `split` equal shares
+    const int per = (H + split - 1) / split;
+    const int t0 = q * per, t1 = min(H, t0 + per);
+    for (int t = t0; t < t1; ++t) {  // irfft (backward norm 1/H), real output
+        const int d = t * A + a;
+        const float v_d = var[d], mu_d = mu[d], ub_d = upper[d], lb_d = lower[d];  // (requested before the transform, used behind it)
         float y = re[0];
-        const int fl = (H & 1) ? NF : NF - 1;  // frequencies with a distinct conjugate partner: 1 .. fl-1
         int ph = 0;
-        for (int f = 1; f < fl; ++f) {
+        // ONE basic block over the NFMAX - 1 frequencies: the table reads of all of them go out together.  (With a branch per
+        // frequency every cs / sn pair was an LDS round trip of its own.)  Frequencies beyond fl - 1 compute on clamped copies and are
+        // dropped by the select: y's sum is the same chain of additions.
+#pragma unroll
+        for (int f = 1; f < NFMAX; ++f) {
             ph += t;
             if (ph >= H) ph -= H;  // (f * t) mod H
-            y += 2.0f * (re[f] * cs[ph] - im[f] * sn[ph]);
+            const float yn = y + 2.0f * (re[f] * cs[ph] - im[f] * sn[ph]);
+            y = f < fl ? yn : y;
         }
-        if ((H & 1) == 0) y += re[NF - 1] * ((t & 1) ? -1.0f : 1.0f);
+        if (even) y += re_last * ((t & 1) ? -1.0f : 1.0f);
         const float noise = y * inv;
-        const int d = t * A + a;
-        float x = noise * sqrtf(var[d]) + mu[d];           // trajectory_opt.py:438-439
-        x = fminf(x, upper[d]);                            // torch.minimum(.., upper)
-        x = fmaxf(x, lower[d]);                            // torch.maximum(.., lower)
+        float x = noise * sqrtf(v_d) + mu_d;               // trajectory_opt.py:438-439
+        x = fminf(x, ub_d);                                // torch.minimum(.., upper)
+        x = fmaxf(x, lb_d);                                // torch.maximum(.., lower)
         population[((size_t)c * H + t) * A + a] = x;
     }
+}
+
+// host side: the instance for the horizon; a series' steps (and draws) dealt to 1 / 2 / 4 threads so that the launch fills the chip
+inline void launch_icem_sample(hipStream_t st, int n_env, int row_stride, int n, int H, int A, float exponent, const float* mu, const float* var,
+                               const float* lower, const float* upper, const float* normals, unsigned long long seed, unsigned long long stream,
+                               float* population) {
+    const long long total = (long long)n_env * n * A;
+    const int split = total >= 65536 ? 1 : (total >= 32768 ? 2 : 4);  // (1 024 SIMDs x 64 lanes)
+    const int NF = H / 2 + 1;
+    const unsigned series = NF > 33 ? 64u : 128u;
+    const dim3 grid((unsigned)((total + series - 1) / series)), block(series * (unsigned)split);
+    const size_t lds = (size_t)2 * NF * series * sizeof(float);
+#define HIPETS_ICEM_LAUNCH(NFM) \
+    hipLaunchKernelGGL(icem_sample_kernel<NFM>, grid, block, lds, st, n_env, row_stride, n, H, A, exponent, mu, var, lower, upper, normals, seed, stream, population)
+    if (NF <= 9) HIPETS_ICEM_LAUNCH(9);
+    else if (NF <= 17) HIPETS_ICEM_LAUNCH(17);
+    else if (NF <= 25) HIPETS_ICEM_LAUNCH(25);
+    else if (NF <= 33) HIPETS_ICEM_LAUNCH(33);
+    else if (NF <= 49) HIPETS_ICEM_LAUNCH(49);
+    else HIPETS_ICEM_LAUNCH(kMaxHorizon / 2 + 1);
+#undef HIPETS_ICEM_LAUNCH
 }
 
 // trajectory_opt.py:450-462: kept elites shifted one step, tail action ~ N(mu[-1], sqrt(var[-1]))

@@ -122,9 +122,9 @@ def test_no_kernel_of_the_shipped_library_uses_scratch_memory():
     zero bytes of scratch.  Register-resident fragment arrays are what the rollout kernel's k loop lives on; one dynamically
     indexed array (a loop the compiler did not unroll) moves them to scratch memory without any diagnostic -- same results,
     28 ms instead of 1 ms per rollout (round 3, caught by timing only) -- and an instantiation too many pushes a kernel that
-    sits at the 256-VGPR limit into spilling.  ONE exception, by design: the coloured-noise sampler keeps its H/2+1 spectrum
-    coefficients in a per-thread array.  (Until round 5 the two R = 2 instances of the bf16x3 arithmetic mode spilt to scratch and
-    were excepted here; they were deleted instead.)"""
+    sits at the 256-VGPR limit into spilling.  No exception is left: until round 6 the coloured-noise sampler kept its H/2+1 spectrum
+    coefficients in a run-time indexed per-thread array (scratch: 72 us per cfg4 iteration) -- its frequency loops are unrolled over
+    registers now; until round 5 the two R = 2 instances of the bf16x3 arithmetic mode spilt to scratch: deleted."""
     import json
     import sys
 
@@ -137,12 +137,9 @@ def test_no_kernel_of_the_shipped_library_uses_scratch_memory():
     rollout = [k for k in kernels if "rollout_kernel" in k]
     assert len(rollout) >= 20, "the resource report of the rollout-kernel instances is missing from the buildinfo file"
 
-    def allowed(name):
-        return "icem_sample_kernel" in name
-
+    assert any("icem_sample_kernel" in k for k in kernels)
     for name, r in kernels.items():
-        if not allowed(name):
-            assert r.get("ScratchSize [bytes/lane]", 0) == 0, (name, r)
+        assert r.get("ScratchSize [bytes/lane]", 0) == 0, (name, r)
 
 
 def test_isa_scanner_sees_both_hazards_of_an_asm_mfma(tmp_path):
