@@ -289,22 +289,25 @@ __host__ __device__ inline void hipets_bound_fail(const int line) {
 #endif
 
 struct NoTail {};  // wave_gemm's TL: the ordinary epilogue (activation, store as the next op's LDS image)
-// A fused tail = three stages over the accumulators (units) a wave finished: prep(slot, c, r) for EVERY unit first -- it only
-// loads (LDS) what the unit will need into its slot, so the round trips of all units overlap --, then unit(slot, acc, c, r)
-// for every unit (arithmetic + stores), then finish() once per wave.
+// A fused tail = four stages over the accumulators (units) a wave finished: prep(slot, c, r) for EVERY unit of a group first -- it
+// only loads (LDS) what the unit will need into its slot, so the round trips of all units overlap --, then draw(slot a, slot b, c_a,
+// c_b, two) for every PAIR of units (the pair's standard normals: one Philox block per lane for the two units together, see
+// rollout_kernel's tail_draw), then unit(slot, acc, c, r) for every unit (arithmetic + stores), then finish() once per wave.
 struct FusedSlot {  // what one unit's lane reads from LDS (rollout_kernel, KSpec::FUSE)
     float mxA, mxB, mnA, mnB, pA, pB;
     double nmA, nmB, nsA, nsB;
     int rid, ndA, ndB;
+    float n0, n1;  // the two standard normals of the lane's dims (draw stage)
 };
-template <class P, class F, class G>
+template <class P, class D, class F, class G>
 struct TailStages {
     P prep;
+    D draw;
     F unit;
     G finish;
 };
-template <class P, class F, class G>
-__device__ __forceinline__ TailStages<P, F, G> make_tail(P p, F f, G g) { return TailStages<P, F, G>{p, f, g}; }
+template <class P, class D, class F, class G>
+__device__ __forceinline__ TailStages<P, D, F, G> make_tail(P p, D d, F f, G g) { return TailStages<P, D, F, G>{p, d, f, g}; }
 
 // ACT >= 0: the activation is a compile-time fact (one epilogue in the code); ACT < 0: `act` selects it at run time.
 // PRE: chunk 0's weight fragments and the biases are already in `pre` (prefetch_issue by the previous op); after the k loop
@@ -863,6 +866,13 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                     const int u = g * kTailGroup + k;
                     if (u < kNUt) tl->prep(slots[k], unit_c(u), unit_r(u));
                 }
+            }
+            static_assert(kTailGroup % 2 == 0, "the draw stage pairs the units of a group");
+#pragma unroll
+            for (int k = 0; k < kTailGroup; k += 2) {
+                const int u = g * kTailGroup + k;
+                if (u + 1 < kNUt) tl->draw(slots[k], slots[k + 1], unit_c(u), unit_c(u + 1), true);
+                else if (u < kNUt) tl->draw(slots[k], slots[k], unit_c(u), unit_c(u), false);
             }
 #pragma unroll
             for (int k = 0; k < kTailGroup; ++k) {
@@ -2574,6 +2584,49 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const int iA = max(0, min(OM::col(d0), md.obs_in - 1)), iB = max(0, min(OM::col(d0 + 1), md.obs_in - 1));
                 q.nmA = sm.nmean[iA]; q.nmB = sm.nmean[iB]; q.nsA = sm.nstd[iA]; q.nsB = sm.nstd[iB];
             };
+            // The standard normals of two units at once.  A lane's two dims (d0 = 8 c + 2 g, d0 + 1) take HALF of Philox block (row, step,
+            // d0 / 4) -- x, y for an even lane group g, z, w for an odd one (exactly rollout_normals4's assignment) -- and the other half
+            // belongs to the lane 16 further (g ^ 1: same row, the block's other two dims).  Until round 6 every lane computed the whole
+            // block of every unit and dropped half of it (the ten rounds are half of a unit's VALU time).  Now, for a PAIR of units (a, b),
+            // the even lane groups compute a's block and the odd ones b's, and each lane fetches the half it lacks from its partner's
+            // registers (two ds_bpermute): one block per lane and pair instead of two.  Same blocks, same halves, same Box-Muller: same bits.
+            // A group's odd unit out (`two` false) draws as before.
+            auto tail_draw = [&](FusedSlot& qa, FusedSlot& qb, const int ca, const int cb, const bool two) __attribute__((always_inline)) {
+#ifndef HIPETS_TIMING_NO_DRAWS
+#define HIPETS_TIMING_NO_DRAWS 0  // 1 = TIMING-ONLY builds (results are wrong on purpose): the tail draws nothing -- an upper bound of what moving
+#endif                            // the draws off the step's critical path (e.g. into the hand-over wait) could gain; profiles/headline_probe.py
+#ifndef HIPETS_SHARED_DRAWS
+#define HIPETS_SHARED_DRAWS 1     // 0 = every lane computes the whole block of every unit (A/B measurements)
+#endif
+                if constexpr (HIPETS_TIMING_NO_DRAWS) {
+                    qa.n0 = 0.37f + 1e-3f * (float)(qa.rid & 7);
+                    qa.n1 = -0.81f;
+                    qb.n0 = 0.37f + 1e-3f * (float)(qb.rid & 7);
+                    qb.n1 = -0.81f;
+                    return;
+                }
+                const int g = lane >> 4;
+                const bool odd = (g & 1) != 0;
+                const uint32_t k0 = (uint32_t)ra.seed, k1 = (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32);
+                if (!two || !HIPETS_SHARED_DRAWS) {
+                    const Philox4 r4 = philox4x32_10((uint32_t)qa.rid, (uint32_t)t, (uint32_t)((8 * ca + 2 * g) >> 2), (uint32_t)ra.stream_id, k0, k1);
+                    box_muller(odd ? r4.z : r4.x, odd ? r4.w : r4.y, qa.n0, qa.n1);
+                    if (two) {
+                        const Philox4 s4 = philox4x32_10((uint32_t)qb.rid, (uint32_t)t, (uint32_t)((8 * cb + 2 * g) >> 2), (uint32_t)ra.stream_id, k0, k1);
+                        box_muller(odd ? s4.z : s4.x, odd ? s4.w : s4.y, qb.n0, qb.n1);
+                    }
+                    return;
+                }
+                const Philox4 r4 = philox4x32_10((uint32_t)(odd ? qb.rid : qa.rid), (uint32_t)t, (uint32_t)((8 * (odd ? cb : ca) + 2 * g) >> 2),
+                                                 (uint32_t)ra.stream_id, k0, k1);
+                // what the partner lacks of this lane's block: an even lane holds a's block, its (odd) partner wants z, w; an odd lane
+                // holds b's block, its (even) partner wants x, y
+                const int partner = ((lane ^ 16) & 63) << 2;
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(odd ? r4.x : r4.z));
+                const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(odd ? r4.y : r4.w));
+                box_muller(odd ? t0 : r4.x, odd ? t1 : r4.y, qa.n0, qa.n1);  // unit a: (x, y) of a's block on even lanes, (z, w) -- from the partner -- on odd ones
+                box_muller(odd ? r4.z : t0, odd ? r4.w : t1, qb.n0, qb.n1);  // unit b: (x, y) of b's block -- from the partner -- on even lanes, (z, w) on odd ones
+            };
             auto tail_unit = [&](const FusedSlot& q, const f32x4 a, const int c, const int r) __attribute__((always_inline)) {
                 const int g = lane >> 4, j = lane & 15;
                 const int s = r * kTile + j;
@@ -2584,20 +2637,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const float mxA = q.mxA, mxB = q.mxB, mnA = q.mnA, mnB = q.mnB, pA = q.pA, pB = q.pB;
                 const bool addA = md.target_is_delta && !q.ndA, addB = md.target_is_delta && !q.ndB;
                 const double nmA = q.nmA, nmB = q.nmB, nsA = q.nsA, nsB = q.nsB;
-                // the two normals of (row, step, dims d0, d0 + 1): half of Philox block d0 / 4, exactly rollout_normals4's
-                float n0, n1;
-#ifndef HIPETS_TIMING_NO_DRAWS
-#define HIPETS_TIMING_NO_DRAWS 0  // 1 = TIMING-ONLY builds (results are wrong on purpose): the tail draws nothing -- an upper bound of what moving
-#endif                            // the draws off the step's critical path (e.g. into the hand-over wait) could gain; profiles/headline_probe.py
-                if constexpr (HIPETS_TIMING_NO_DRAWS) {
-                    n0 = 0.37f + 1e-3f * (float)(rid & 7);
-                    n1 = -0.81f;
-                } else {
-                    const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)(d0 >> 2), (uint32_t)ra.stream_id, (uint32_t)ra.seed,
-                                                     (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32));
-                    const bool upper = (d0 & 2) != 0;
-                    box_muller(upper ? r4.z : r4.x, upper ? r4.w : r4.y, n0, n1);
-                }
+                const float n0 = q.n0, n1 = q.n1;  // the two normals of (row, step, dims d0, d0 + 1): tail_draw
                 float lvA = a[2], lvB = a[3];
                 lvA = mxA - softplus_fast(mxA - lvA);  // gaussian_mlp.py:152
                 lvB = mxB - softplus_fast(mxB - lvB);
@@ -2704,7 +2744,7 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 }
             };
             auto tail_finish = [&]() __attribute__((always_inline)) {};
-            const auto tail = make_tail(tail_prep, tail_unit, tail_finish);
+            const auto tail = make_tail(tail_prep, tail_draw, tail_unit, tail_finish);
             prof.mark(12);
             if constexpr (kRagged) {
                 if (one_tile) mlp_output_layer_fused<1, S>(md, sm.lmeta, member, cur, wave, lane, prof, tail, sm.part);
