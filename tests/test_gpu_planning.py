@@ -313,6 +313,37 @@ def test_icem_kernels_and_optimizer_match_reference_two_calls(engine):
     assert tuple(opt.elite.shape) == (int(opt.elite_num), H, A)
 
 
+# every NFMAX instance of the sampler (horizons up to 16 / 32 / 48 / 64 / 96 / 128), even and odd horizons (the Nyquist term exists for even ones
+# only), and the three ways a series' steps are dealt to threads (n x A >= 65 536: one thread per series; >= 32 768: two; below: four)
+ICEM_SHAPES = [(3, 50, 2), (8, 700, 3), (15, 64, 17), (16, 33, 5), (17, 2000, 17), (31, 129, 6), (33, 40, 7), (40, 1036, 17), (47, 300, 2), (48, 17, 17),
+               (64, 70000, 1), (65, 33, 3), (96, 40, 6), (97, 8200, 4), (127, 20, 2), (128, 300, 1)]
+
+
+@pytest.mark.parametrize("H,n,A", ICEM_SHAPES, ids=[f"H{h}_n{n}_A{a}" for h, n, a in ICEM_SHAPES])
+def test_icem_sampler_instances_match_reference_irfft(engine, H, n, A):
+    """powerlaw_psd_gaussian (util/math.py:318-396) from injected spectrum normals against the oracle's torch.fft.irfft form, for every
+    instance of the device sampler (coefficients in registers, frequency loop unrolled over NFMAX, padded frequencies dropped by a
+    select) and every split of a series' time steps over threads; mean / std / bounds applied as trajectory_opt.py:433-441 does."""
+    g = torch.Generator().manual_seed(H * 1000 + A)
+    normals = torch.randn(2, n, A, H // 2 + 1, generator=g)
+    ref = po.powerlaw_psd_gaussian(1.5, size=(n, A, H), normals=(normals[0], normals[1])).transpose(1, 2)
+    mu = torch.randn(H, A, generator=g) * 0.3
+    var = torch.rand(H, A, generator=g) + 0.1
+    lo, hi = -torch.ones(H, A), torch.ones(H, A) * 0.8
+    want = torch.maximum(torch.minimum(ref * var.sqrt() + mu, hi), lo)
+    out = torch.full((n, H, A), float("nan"), device=DEV)
+    engine.icem_sample(n, H, A, 1.5, mu.to(DEV), var.to(DEV), lo.to(DEV), hi.to(DEV), out, normals=normals.to(DEV).contiguous())
+    assert torch.allclose(out.cpu(), want, rtol=1e-5, atol=2e-5)
+    # in-kernel draws: every element written, deterministic in (seed, stream), different across streams
+    a = torch.full((n, H, A), float("nan"), device=DEV)
+    b = torch.empty_like(a)
+    engine.icem_sample(n, H, A, 1.5, mu.to(DEV), var.to(DEV), lo.to(DEV), hi.to(DEV), a, seed=5, stream_id=2)
+    engine.icem_sample(n, H, A, 1.5, mu.to(DEV), var.to(DEV), lo.to(DEV), hi.to(DEV), b, seed=5, stream_id=2)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    engine.icem_sample(n, H, A, 1.5, mu.to(DEV), var.to(DEV), lo.to(DEV), hi.to(DEV), b, seed=5, stream_id=3)
+    assert not torch.equal(a, b)
+
+
 def test_icem_and_mppi_with_engine_objective(engine):
     """iCEM (cfg4-like: 7 members / 5 elites, Appendix B7) and MPPI driving the fused rollout objective."""
     from hipets.planning import _BoundObjective
@@ -567,12 +598,19 @@ def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
         assert np.allclose(agent.optimizer.previous_solution.cpu().numpy(), a["shifted_plans"][t].numpy(), rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("pop,K,ties", [(4000, 400, False), (2000, 200, True), (8192, 820, False), (1500, 1, True), (3000, 1500, False)])
-def test_refit_large_populations_select_path(engine, pop, K, ties):
+# (H, A): the plan's H x A dimensions are dealt to up to 8 workgroups in slices of <= 128 (cem.hpp, round 6), eight threads per dimension, a
+# thread's share of the K elites held in registers (2 / 4 / 8 / 16 per thread) or walked 16 at a time (K > 128): every tier, one and several
+# workgroups, populations on both sides of the rank-counting / radix-select switch
+REFIT_SHAPES = [(4000, 400, False, 5, 3), (2000, 200, True, 5, 3), (8192, 820, False, 5, 3), (1500, 1, True, 5, 3), (3000, 1500, False, 5, 3),
+                (500, 50, False, 30, 6), (500, 12, True, 30, 6), (1036, 103, False, 40, 17), (1036, 30, True, 40, 17), (600, 300, False, 40, 17),
+                (350, 35, False, 25, 7), (100, 10, True, 15, 1), (640, 64, True, 50, 24), (641, 7, False, 50, 24)]
+
+
+@pytest.mark.parametrize("pop,K,ties,H,A", REFIT_SHAPES, ids=[f"pop{c[0]}_K{c[1]}_{'ties_' if c[2] else ''}D{c[3] * c[4]}" for c in REFIT_SHAPES])
+def test_refit_large_populations_select_path(engine, pop, K, ties, H, A):
     """Populations of sharded multi-GPU plans (pop 500 x 8 ranks) and beyond: the top-k is a radix select + a sort of the
     elites (a full bitonic sort when K > 1024).  Elite indices in order (ties -> lower index first, NaN -> -1e-10 first),
     refit statistics and best-so-far against torch / f64."""
-    H, A = 5, 3
     g = torch.Generator().manual_seed(pop)
     values = torch.randn(pop, generator=g)
     if ties:
