@@ -1576,7 +1576,12 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
             if (check_cem(&cp)) return 1;
             int n2 = 1;
             while (n2 < rows) n2 <<= 1;
-            hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks((int)nd), n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, make_cem(&cp, n_env),
+            CemDev cr = make_cem(&cp, n_env);
+            if (!sharded) {  // the rollouts left their per-row totals: the particle means are formed inside the refit kernel (same sum, same bits)
+                cr.totals = e->totals.as<float>();
+                cr.P = P;
+            }
+            hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks((int)nd), n_env), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, cr,
                                e->values.as<float>(), popbuf, e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                                e->best_solution.as<float>(), e->elite_idx.as<int>());
             HCHECK(hipGetLastError());
@@ -1594,7 +1599,7 @@ int plan_icem_impl(hipets_engine* e, const hipets_icem_params* p, int32_t n_env,
         if (sharded) {
             if (sharded_evaluate(e, popbuf, rows, H, P, &ro, stream, &le)) return 1;
         } else if (le.ok()) {
-            le.note(rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, e->values.as<float>(), stream));  // s0 staged above
+            le.note(rollout_impl(e, popbuf, nullptr, n_env * rows, H, P, &ro, nullptr, stream));  // s0 staged above; returns: refit (CemDev::totals)
         }
         if (le.ok()) le.note(refit());
         if (!sharded && !le.ok()) break;
@@ -1687,14 +1692,13 @@ int hipets_planet_set_model(hipets_engine* e, const hipets_planet_desc* d, void*
     return 0;
 }
 
-int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop, int32_t H,
-                          int32_t P, const hipets_planet_opts* o, float* returns, void* stream) {
-    if (!e || !e->has_planet) return fail("engine has no PlaNet model (call hipets_planet_set_model)");
-    if (!actions || !latent0 || !belief0 || !o || !returns) return fail("null argument");
-    if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    HCHECK(hipSetDevice(e->device));
-    ENTER_STREAM(e, st);
+}  // extern "C"
+
+namespace {
+// hipets_planet_rollout; returns == nullptr: the caller reduces e->totals over the particles itself (hipets_plan_planet_cem: inside the
+// refit kernel, CemDev::totals)
+int planet_rollout_impl(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop, int32_t H,
+                        int32_t P, const hipets_planet_opts* o, float* returns, hipStream_t st) {
     const long long B = (long long)pop * P;
     if (B > 0x7FFFFFFF / std::max(e->pd.belief, 16)) return fail("batch too large");
     if (e->totals.ensure((size_t)B * 4)) return 1;
@@ -1717,9 +1721,24 @@ int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* l
     // (HIPETS_PLANET_GENERIC=1: the run-time generic instance whatever the shapes -- tests compare the two bit for bit)
     const char* pg = std::getenv("HIPETS_PLANET_GENERIC");
     HCHECK(launch_planet_rollout(nwg, (unsigned)lds, (int)e->lds_max, e->pd, ra, st, e->planet_static && !(pg && pg[0] == '1')));
+    if (!returns) return 0;
     hipLaunchKernelGGL(particle_mean_kernel, dim3((pop + 255) / 256), dim3(256), 0, st, e->totals.as<float>(), returns, pop, P);
     HCHECK(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int hipets_planet_rollout(hipets_engine* e, const float* actions, const float* latent0, const float* belief0, int32_t pop, int32_t H,
+                          int32_t P, const hipets_planet_opts* o, float* returns, void* stream) {
+    if (!e || !e->has_planet) return fail("engine has no PlaNet model (call hipets_planet_set_model)");
+    if (!actions || !latent0 || !belief0 || !o || !returns) return fail("null argument");
+    if (pop < 1 || H < 1 || P < 1) return fail("bad pop/horizon/particles");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HCHECK(hipSetDevice(e->device));
+    ENTER_STREAM(e, st);
+    return planet_rollout_impl(e, actions, latent0, belief0, pop, H, P, o, returns, st);
 }
 
 int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const float* x0, const float* lower, const float* upper,
@@ -1729,6 +1748,7 @@ int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const f
     if (check_cem(p)) return 1;
     if (!x0 || !lower || !upper || !latent0 || !belief0 || !out) return fail("null argument");
     if (p->act_dim != e->pd.action) return fail("act_dim %d != model action_size %d", p->act_dim, e->pd.action);
+    if (P < 1) return fail("bad pop/horizon/particles");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     HCHECK(hipSetDevice(e->device));
     ENTER_STREAM(e, st);
@@ -1752,9 +1772,14 @@ int hipets_plan_planet_cem(hipets_engine* e, const hipets_cem_params* p, const f
                            lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid, e->population.as<float>());
         HCHECK(hipGetLastError());
         po.stream_id = sid;
-        if (hipets_planet_rollout(e, e->population.as<float>(), latent0, belief0, c.pop, c.H, P, &po, e->values.as<float>(), stream)) return 1;
+        // (the particle means of the returns are formed inside the refit kernel -- the same sequential sum and division as
+        // particle_mean_kernel, so the same bits -- instead of a launch of its own in between: round 6)
+        if (planet_rollout_impl(e, e->population.as<float>(), latent0, belief0, c.pop, c.H, P, &po, nullptr, st)) return 1;
         int* eidx = (e->has_trace && e->trace.elite_idx) ? e->trace.elite_idx + (size_t)i * c.K : nullptr;
-        hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, c, e->values.as<float>(),
+        CemDev cr = c;
+        cr.totals = e->totals.as<float>();
+        cr.P = P;
+        hipLaunchKernelGGL(cem_refit_kernel, dim3(refit_blocks(c.D), 1), dim3(kRefitThreads), (size_t)n2 * 8 + kRefitScratchBytes, st, cr, e->values.as<float>(),
                            e->population.as<float>(), e->mu.as<float>(), e->disp.as<float>(), e->best_value.as<float>(),
                            e->best_solution.as<float>(), eidx);
         HCHECK(hipGetLastError());
