@@ -261,7 +261,10 @@ int hipets_device_perms(hipets_engine* e, int32_t horizon, int32_t batch, uint64
  *     error from its NEXT rollout / plan call instead.
  * The persistent form assumes what the reference's deployment gives it -- one planning process per GPU; on = 0 forces per-step
  * launches (also: env HIPETS_NO_PERSISTENT=1).  Env HIPETS_MAX_WORKGROUPS=n caps the workgroups of a persistent launch at n (the
- * rest of the batch is served in turns, as when the chip is the limit): processes that share a GPU can leave each other room.   */
+ * rest of the batch is served in turns, as when the chip is the limit): processes that share a GPU can leave each other room.
+ * (The wide-output instances -- Humanoid-v4: 752 output columns, two row tiles per workgroup -- deal the LAST turn of a step in one-tile
+ * workgroups when the row tiles left for it fit one per launched workgroup; same results bit for bit, a shorter step.  Env
+ * HIPETS_RAGGED_LAST_TURN=0 keeps two-tile turns throughout: A/B measurements.)                                               */
 int hipets_set_persistent(hipets_engine* e, int32_t on);
 int hipets_set_handover_timeout(hipets_engine* e, double seconds);
 int hipets_check_async_error(hipets_engine* e, int32_t* timed_out);

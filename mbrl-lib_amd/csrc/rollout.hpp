@@ -334,6 +334,9 @@ __device__ __forceinline__ TailStages<P, D, F, G> make_tail(P p, D d, F f, G g) 
 #ifndef HIPETS_INTERLEAVE
 #define HIPETS_INTERLEAVE 1  // the next chunk's fragment loads inside the MFMAs' shadows (compute_il in wave_gemm)
 #endif
+#ifndef HIPETS_SHARED_DRAWS
+#define HIPETS_SHARED_DRAWS 1  // fused tail: one Philox block per lane and PAIR of units (rollout_kernel tail_draw); 0 = every lane computes the whole block of every unit (A/B measurements)
+#endif
 #ifndef HIPETS_KS_TRIPLE
 #define HIPETS_KS_TRIPLE 1  // k-split (one-tile) instances: fragments fetched TWO chunks ahead (three register sets, wave_gemm kTriple)
 #endif
@@ -868,17 +871,19 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ in, float* _
                 }
             }
             static_assert(kTailGroup % 2 == 0, "the draw stage pairs the units of a group");
+            // (pair by pair -- draw, unit, unit -- so that only one pair's normals are live at a time: with the whole group's drawn up front
+            // three two-workgroups-per-CU instances spilt to scratch memory)
 #pragma unroll
             for (int k = 0; k < kTailGroup; k += 2) {
                 const int u = g * kTailGroup + k;
                 if (u + 1 < kNUt) tl->draw(slots[k], slots[k + 1], unit_c(u), unit_c(u + 1), true);
                 else if (u < kNUt) tl->draw(slots[k], slots[k], unit_c(u), unit_c(u), false);
-            }
 #pragma unroll
-            for (int k = 0; k < kTailGroup; ++k) {
-                const int u = g * kTailGroup + k;
-                if (u < CT * R) tl->unit(slots[k], acc[(u < CT * R ? u : 0) / R][(u < CT * R ? u : 0) % R], unit_c(u), unit_r(u));
-                else if (u < kNUt) tl->unit(slots[k], accx[(u >= CT * R && u < kNUt) ? u - CT * R : 0], unit_c(u), unit_r(u));
+                for (int kk = k; kk < k + 2; ++kk) {
+                    const int uu = g * kTailGroup + kk;
+                    if (uu < CT * R) tl->unit(slots[kk], acc[(uu < CT * R ? uu : 0) / R][(uu < CT * R ? uu : 0) % R], unit_c(uu), unit_r(uu));
+                    else if (uu < kNUt) tl->unit(slots[kk], accx[(uu >= CT * R && uu < kNUt) ? uu - CT * R : 0], unit_c(uu), unit_r(uu));
+                }
             }
         }
         tl->finish();
@@ -2590,14 +2595,23 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
             // block of every unit and dropped half of it (the ten rounds are half of a unit's VALU time).  Now, for a PAIR of units (a, b),
             // the even lane groups compute a's block and the odd ones b's, and each lane fetches the half it lacks from its partner's
             // registers (two ds_bpermute): one block per lane and pair instead of two.  Same blocks, same halves, same Box-Muller: same bits.
-            // A group's odd unit out (`two` false) draws as before.
+            // A group's odd unit out (`two` false) draws as before.  Three instances keep the draw inside tail_unit: the two-tile DEVICE-mode
+            // instances with obs preprocessing or a learned reward (pets_halfcheetah, pets_pusher / pets_reacher, pets_mppi_halfcheetah in
+            // DEVICE mode) sit at the 256-register limit of two workgroups per CU, and with the pair's exchange they spilt 3-14 registers to
+            // scratch memory (the build's resource report; pets_halfcheetah 0.498 -> 0.487 of peak; tests/test_abi.py allows no kernel any).
+            constexpr bool kPairDraws = HIPETS_SHARED_DRAWS != 0 &&
+                                        !(MinWaves<R, S>::value == 2 && R == 2 && S::KMODE != HIPETS_MODE_FAST && (S::OBSP != HIPETS_OBS_NONE || S::REW == HIPETS_REW_LEARNED));
+            auto unit_draw = [&](const int rid, const int c, float& n0, float& n1) __attribute__((always_inline)) {  // one unit, the whole block per lane
+                const int g = lane >> 4;
+                const bool odd = (g & 1) != 0;
+                const Philox4 r4 = philox4x32_10((uint32_t)rid, (uint32_t)t, (uint32_t)((8 * c + 2 * g) >> 2), (uint32_t)ra.stream_id, (uint32_t)ra.seed,
+                                                 (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32));
+                box_muller(odd ? r4.z : r4.x, odd ? r4.w : r4.y, n0, n1);
+            };
             auto tail_draw = [&](FusedSlot& qa, FusedSlot& qb, const int ca, const int cb, const bool two) __attribute__((always_inline)) {
 #ifndef HIPETS_TIMING_NO_DRAWS
 #define HIPETS_TIMING_NO_DRAWS 0  // 1 = TIMING-ONLY builds (results are wrong on purpose): the tail draws nothing -- an upper bound of what moving
 #endif                            // the draws off the step's critical path (e.g. into the hand-over wait) could gain; profiles/headline_probe.py
-#ifndef HIPETS_SHARED_DRAWS
-#define HIPETS_SHARED_DRAWS 1     // 0 = every lane computes the whole block of every unit (A/B measurements)
-#endif
                 if constexpr (HIPETS_TIMING_NO_DRAWS) {
                     qa.n0 = 0.37f + 1e-3f * (float)(qa.rid & 7);
                     qa.n1 = -0.81f;
@@ -2605,16 +2619,12 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                     qb.n1 = -0.81f;
                     return;
                 }
+                if constexpr (!kPairDraws) return;  // (drawn by tail_unit)
                 const int g = lane >> 4;
                 const bool odd = (g & 1) != 0;
                 const uint32_t k0 = (uint32_t)ra.seed, k1 = (uint32_t)(ra.seed >> 32) ^ (uint32_t)(ra.stream_id >> 32);
-                if (!two || !HIPETS_SHARED_DRAWS) {
-                    const Philox4 r4 = philox4x32_10((uint32_t)qa.rid, (uint32_t)t, (uint32_t)((8 * ca + 2 * g) >> 2), (uint32_t)ra.stream_id, k0, k1);
-                    box_muller(odd ? r4.z : r4.x, odd ? r4.w : r4.y, qa.n0, qa.n1);
-                    if (two) {
-                        const Philox4 s4 = philox4x32_10((uint32_t)qb.rid, (uint32_t)t, (uint32_t)((8 * cb + 2 * g) >> 2), (uint32_t)ra.stream_id, k0, k1);
-                        box_muller(odd ? s4.z : s4.x, odd ? s4.w : s4.y, qb.n0, qb.n1);
-                    }
+                if (!two) {
+                    unit_draw(qa.rid, ca, qa.n0, qa.n1);
                     return;
                 }
                 const Philox4 r4 = philox4x32_10((uint32_t)(odd ? qb.rid : qa.rid), (uint32_t)t, (uint32_t)((8 * (odd ? cb : ca) + 2 * g) >> 2),
@@ -2637,7 +2647,8 @@ __global__ __launch_bounds__(kThreads, (MinWaves<R, S>::value)) void rollout_ker
                 const float mxA = q.mxA, mxB = q.mxB, mnA = q.mnA, mnB = q.mnB, pA = q.pA, pB = q.pB;
                 const bool addA = md.target_is_delta && !q.ndA, addB = md.target_is_delta && !q.ndB;
                 const double nmA = q.nmA, nmB = q.nmB, nsA = q.nsA, nsB = q.nsB;
-                const float n0 = q.n0, n1 = q.n1;  // the two normals of (row, step, dims d0, d0 + 1): tail_draw
+                float n0 = q.n0, n1 = q.n1;  // the two normals of (row, step, dims d0, d0 + 1): tail_draw ...
+                if constexpr (!kPairDraws && !HIPETS_TIMING_NO_DRAWS) unit_draw(rid, c, n0, n1);  // ... or drawn here (two workgroups per CU)
                 float lvA = a[2], lvB = a[3];
                 lvA = mxA - softplus_fast(mxA - lvA);  // gaussian_mlp.py:152
                 lvB = mxB - softplus_fast(mxB - lvB);

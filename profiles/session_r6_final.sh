@@ -16,6 +16,7 @@ grep -h '"metric"' $OUT/bench_gloo2.log | tail -1 > $OUT/bench_line_gloo2.json
 HIPETS_LIB=$PWD/profiles/variants/leanprof.so run phase_profile python profiles/one_tile_phase_profile.py
 grep -h '^{"lib"' $OUT/phase_profile.log | tail -1 > $OUT/one_tile_phase_profile.json
 HIPETS_LIB=$PWD/profiles/variants/steptrace.so run turn_trace python profiles/turn_trace.py
+HIPETS_LIB=$PWD/profiles/variants/steptrace.so TRACE_CASES=cfg4p_pop497:376:2:2:497,cfg4p_pop1001:376:2:3:1001 run turn_trace_ragged python profiles/turn_trace.py
 run cfg4p_iterations python profiles/cfg4p_iteration_probe.py
 grep -h '^{"obs"' $OUT/cfg4p_iterations.log | tail -1 > $OUT/cfg4p_iterations.json
 run small_batches python profiles/small_batch_probe.py
