@@ -83,6 +83,9 @@ __global__ void cem_sample_kernel(const CemDev p, const float* __restrict__ mu, 
 // (descending, ties broken by lower index: rank counting for small populations, a radix select + a sort of the elites for
 // larger ones, a full bitonic network when K > kSelectMaxK), then threads share the dimensions d of the [H,A] plan and
 // reduce the K elites in f64.
+#ifndef HIPETS_REFIT_SKIP
+#define HIPETS_REFIT_SKIP 0  // TIMING-ONLY builds (results are wrong on purpose; profiles/r6_refit_phases.json): bit 0 = no particle means, bit 1 = no selection, bit 2 = no mean / variance sweeps
+#endif
 constexpr int kRefitThreads = 1024;
 constexpr int kMaxPop = 8192;
 constexpr int kRefitScratchBytes = 12288;  // LDS behind the key / index arrays: f64 partial sums, or the selection's work space
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
     {  // gridDim.y environments (gridDim.x workgroups each): rebase every pointer to this environment's slice
         const int env = blockIdx.y;
         values += (size_t)env * p.pop;
-        if (p.totals) {
+        if (p.totals && !(HIPETS_REFIT_SKIP & 1)) {
             const float* tot = p.totals + (size_t)env * p.pop * p.P;
             for (int i = threadIdx.x; i < p.pop; i += kRefitThreads) {
                 float s = 0.f;  // the same sequential sum; a candidate's particle totals fetched eight at a time
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
         for (int k = tid; k < p.K; k += kRefitThreads) idx[k] = in_range(elite_in[k]);
         if (tid == 0) key[0] = top_key;  // key[] is only consulted at position 0 from here on
         __syncthreads();
+    } else if (HIPETS_REFIT_SKIP & 2) {  // (timing-only: no selection, the identity order)
     } else if (p.pop <= kRankSortMax) {
         // small populations (every PETS config): rank by counting -- element i sits at position #{j before i}.  One pass of
         // pop LDS broadcast reads per element and a single barrier instead of the ~log^2(n)/2 barrier stages of the
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(kRefitThreads) void cem_refit_kernel(const CemDev p
 #pragma unroll
         for (int u = 0; u < kBestHold; ++u) best_row[u] = population[(size_t)top_i * p.D + min(tid + u * kRefitThreads, p.D - 1)];
     }
-    for (int base = d_lo; base < d_hi; base += G) {
+    for (int base = d_lo; base < ((HIPETS_REFIT_SKIP & 4) ? d_lo : d_hi); base += G) {
         using T = std::true_type;
         using F = std::false_type;
         if (nu <= 2) sweep(base, std::integral_constant<int, 2>{}, T{});

@@ -603,7 +603,9 @@ def test_agent_act_reproduces_the_reference_agent_under_fixed_seeds(case):
 # workgroups, populations on both sides of the rank-counting / radix-select switch
 REFIT_SHAPES = [(4000, 400, False, 5, 3), (2000, 200, True, 5, 3), (8192, 820, False, 5, 3), (1500, 1, True, 5, 3), (3000, 1500, False, 5, 3),
                 (500, 50, False, 30, 6), (500, 12, True, 30, 6), (1036, 103, False, 40, 17), (1036, 30, True, 40, 17), (600, 300, False, 40, 17),
-                (350, 35, False, 25, 7), (100, 10, True, 15, 1), (640, 64, True, 50, 24), (641, 7, False, 50, 24)]
+                (350, 35, False, 25, 7), (100, 10, True, 15, 1), (640, 64, True, 50, 24), (641, 7, False, 50, 24),
+                # rank counting four keys to an LDS read with wave-uniform bounds (round 6): populations around the 64-element wave blocks, ties on
+                (130, 13, True, 5, 3), (65, 6, True, 5, 3), (257, 25, True, 5, 3), (63, 6, True, 5, 3), (3, 2, False, 2, 2), (2, 1, False, 2, 2)]
 
 
 @pytest.mark.parametrize("pop,K,ties,H,A", REFIT_SHAPES, ids=[f"pop{c[0]}_K{c[1]}_{'ties_' if c[2] else ''}D{c[3] * c[4]}" for c in REFIT_SHAPES])
@@ -615,7 +617,7 @@ def test_refit_large_populations_select_path(engine, pop, K, ties, H, A):
     values = torch.randn(pop, generator=g)
     if ties:
         values = (values * 4).round() / 4  # many exact duplicates, also across the elite threshold
-        values[5] = float("nan"); values[77] = float("nan")
+        values[5] = float("nan"); values[min(77, pop - 1)] = float("nan")
     population = torch.randn(pop, H, A, generator=g)
     p = hipets.Engine.cem_params(pop, H, A, 1, K, 0.1, True, False, True)
     mu, disp = torch.zeros(H, A, device=DEV), torch.ones(H, A, device=DEV)
