@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -235,6 +236,44 @@ int choose_R(const hipets_engine* e, long long tiles_total_per_slice, int slices
         }
     }
     return best;
+}
+
+// MPPI sampling (optim.hpp): whole candidates staged in LDS where one fits, else one thread per series
+int launch_mppi_sample(int n_env, int pop, int H, int A, float beta, const float* mean, const float* past_action, const float* lower, const float* upper,
+                       const float* z, uint64_t seed, uint64_t stream_id, float* population, hipStream_t st) {
+    const long long npop = (long long)n_env * pop;
+    const long long D = (long long)H * A;
+    if (D <= kMppiSampleMaxD) {
+        const int G = mppi_sample_group(npop, (int)D);
+        hipLaunchKernelGGL(mppi_sample_staged_kernel, dim3((unsigned)((npop + G - 1) / G)), dim3(kMppiSampleThreads), (size_t)G * D * 4, st, n_env, pop, H, A, G, beta,
+                           mean, past_action, lower, upper, z, (unsigned long long)seed, (unsigned long long)stream_id, population);
+    } else {
+        const long long n = npop * A;
+        hipLaunchKernelGGL(mppi_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_env, pop, H, A, beta, mean, past_action, lower, upper, z,
+                           (unsigned long long)seed, (unsigned long long)stream_id, population);
+    }
+    HCHECK(hipGetLastError());
+    return 0;
+}
+
+// MPPI update (optim.hpp): the weighted sum stages the population through LDS tiles as large as the CU holds -- the kernel opts in to the
+// full LDS once per device, like the rollout kernels
+int launch_mppi_update(hipets_engine* e, int n_env, int pop, int D, float gamma, float* values, const float* population, float* mean, hipStream_t st) {
+    static std::atomic<bool> attr_set[64] = {};
+    const int dev = e->device;
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_update_kernel<kMppiTileMax / 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_max));
+        HCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mppi_update_kernel<kMppiTileMax / 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_max));
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int tile_c = mppi_update_tile(pop, e->lds_max);
+    const dim3 grid(mppi_update_blocks(D), n_env);
+    if (tile_c == kMppiTileMax)
+        hipLaunchKernelGGL(mppi_update_kernel<kMppiTileMax / 16>, grid, dim3(kMppiThreads), mppi_update_smem(pop, tile_c), st, pop, D, gamma, values, population, mean);
+    else
+        hipLaunchKernelGGL(mppi_update_kernel<kMppiTileMax / 32>, grid, dim3(kMppiThreads), mppi_update_smem(pop, tile_c), st, pop, D, gamma, values, population, mean);
+    HCHECK(hipGetLastError());
+    return 0;
 }
 
 // copy `bytes` of caller HOST memory to `dst` on `st`: memcpy into the next pinned slot of the engine's ring, async copy from
@@ -1257,12 +1296,7 @@ int hipets_mppi_sample(hipets_engine* e, int32_t pop, int32_t H, int32_t A, doub
     if (!e || !mean || !past_action || !lower || !upper || !population) return fail("null argument");
     if (pop < 1 || H < 1 || A < 1) return fail("bad pop/horizon/act_dim");
     HCHECK(hipSetDevice(e->device));
-    const int n = pop * A;
-    hipLaunchKernelGGL(mppi_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), 1, pop, H, A,
-                       (float)beta, mean, past_action, lower, upper, z, (unsigned long long)seed, (unsigned long long)stream_id,
-                       population);
-    HCHECK(hipGetLastError());
-    return 0;
+    return launch_mppi_sample(1, pop, H, A, (float)beta, mean, past_action, lower, upper, z, seed, stream_id, population, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hipets_mppi_update(hipets_engine* e, int32_t pop, int32_t H, int32_t A, double gamma, float* values, const float* population,
@@ -1270,10 +1304,7 @@ int hipets_mppi_update(hipets_engine* e, int32_t pop, int32_t H, int32_t A, doub
     if (!e || !values || !population || !mean) return fail("null argument");
     if (pop < 1 || pop > 12000 || H < 1 || A < 1) return fail("population_size %d outside [1, 12000]", pop);
     HCHECK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(mppi_update_kernel, dim3(mppi_update_blocks(H * A), 1), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4,
-                       reinterpret_cast<hipStream_t>(stream), pop, H * A, (float)gamma, values, population, mean);
-    HCHECK(hipGetLastError());
-    return 0;
+    return launch_mppi_update(e, 1, pop, H * A, (float)gamma, values, population, mean, reinterpret_cast<hipStream_t>(stream));
 }
 
 int hipets_icem_sample(hipets_engine* e, int32_t n, int32_t H, int32_t A, double exponent, const float* mu, const float* var,
@@ -1419,17 +1450,11 @@ int plan_mppi_impl(hipets_engine* e, int32_t pop, int32_t H, int32_t A, int32_t 
     for (int k = 0; k < num_iterations; ++k) {
         const uint64_t sid = plan_id * (uint64_t)num_iterations + (uint64_t)k;
         auto sample = [&]() -> int {
-            const long long n = (long long)npop * A;
-            hipLaunchKernelGGL(mppi_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_env, pop, H, A, (float)beta, mean,
-                               e->past_action.as<float>(), lower, upper, (const float*)nullptr, (unsigned long long)seed, (unsigned long long)sid,
-                               e->population.as<float>());  // sharded: identical on every rank (same seed, same counters)
-            HCHECK(hipGetLastError());
-            return 0;
+            return launch_mppi_sample(n_env, pop, H, A, (float)beta, mean, e->past_action.as<float>(), lower, upper, nullptr, seed, sid,
+                                      e->population.as<float>(), st);  // sharded: identical on every rank (same seed, same counters)
         };
         auto update = [&]() -> int {
-            hipLaunchKernelGGL(mppi_update_kernel, dim3(mppi_update_blocks((int)nd), n_env), dim3(kMppiThreads), (size_t)(pop + kMppiThreads) * 4, st, pop, (int)nd, (float)gamma,
-                               e->values.as<float>(), e->population.as<float>(), mean);
-            HCHECK(hipGetLastError());
+            if (launch_mppi_update(e, n_env, pop, (int)nd, (float)gamma, e->values.as<float>(), e->population.as<float>(), mean, st)) return 1;
             return trace_iter(e, k, (int)npop, nd, e->population.as<float>(), e->values.as<float>(), mean, nullptr, st, n_env);
         };
         if (le.ok()) le.note(sample());

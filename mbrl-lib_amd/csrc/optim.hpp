@@ -7,6 +7,8 @@
 // These are HBM/latency-bound elementwise kernels (populations are a few hundred KB); they exist so that a
 // plan never leaves the device, not because they are hot.
 #pragma once
+#include <algorithm>
+
 #include "cem.hpp"
 #include "common.hpp"
 
@@ -40,13 +42,68 @@ __global__ void mppi_sample_kernel(int n_env, int pop, int H, int A, float beta,
     }
 }
 
+// The same population, dealt differently (round 6): the kernel above walks a series' horizon with a rejection-sampled draw inside every step of
+// the recurrence and scatters its stores (28.5 us for pop 2 000 x H 50 x A 6).  Here a workgroup takes G whole candidates: every thread draws
+// for the elements tid, tid + 256, .. of their [G][H][A] block (the draws do not depend on each other: same counters, same values), the
+// recurrence -- now a multiply-add and two compares per step -- runs over the block in LDS, one thread per series, and the block leaves in
+// coalesced stores.  Same expressions in the same order: same bits.
+constexpr int kMppiSampleThreads = 256;
+constexpr int kMppiSampleMaxD = 12288;  // [H x A] floats of one candidate that this form stages (48 KB); beyond: the kernel above
+inline int mppi_sample_group(const long long npop, const int D) {  // candidates per workgroup: >= ~512 workgroups, <= 48 KB of LDS
+    return (int)std::max<long long>(1, std::min<long long>(npop / 512, kMppiSampleMaxD / D));
+}
+__global__ __launch_bounds__(kMppiSampleThreads) void mppi_sample_staged_kernel(int n_env, int pop, int H, int A, int G, float beta, const float* __restrict__ mean,
+                                                                                const float* __restrict__ past_action, const float* __restrict__ lower,
+                                                                                const float* __restrict__ upper, const float* __restrict__ z_in,
+                                                                                unsigned long long seed, unsigned long long stream, float* __restrict__ population) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* zs = reinterpret_cast<float*>(smem);  // [G][H][A]
+    const int tid = threadIdx.x, D = H * A;
+    const long long c_first = (long long)blockIdx.x * G;
+    const int nc = (int)std::min<long long>(G, (long long)n_env * pop - c_first);
+    const int n = nc * D;
+    const long long base = c_first * D;
+    for (int e = tid; e < n; e += kMppiSampleThreads) {
+        const long long idx = base + e;
+        zs[e] = z_in ? z_in[idx] : philox_trunc_normal((uint32_t)idx, (uint32_t)(idx >> 32), seed, stream);
+    }
+    __syncthreads();
+    const float omb = 1.0f - beta;
+    for (int q = tid; q < nc * A; q += kMppiSampleThreads) {
+        const int cl = q / A, a = q % A;
+        const int env = (int)((c_first + cl) / pop);
+        const float* const mn = mean + (size_t)env * D;
+        float prev = past_action[(size_t)env * A + a];
+        float* const ser = zs + (size_t)cl * D + a;
+        for (int h = 0; h < H; ++h) {
+            const float x = beta * (mn[h * A + a] + ser[h * A]) + omb * prev;  // :279-287
+            prev = x;
+            const float ub = upper[h * A + a], lb = lower[h * A + a];
+            float y = x > ub ? ub : x;  // torch.where(population > upper, upper, population)
+            y = y < lb ? lb : y;
+            ser[h * A] = y;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += kMppiSampleThreads) population[base + e] = zs[e];
+}
+
 // trajectory_opt.py:296-309: NaN -> -1e-10; w = exp(gamma (v - max v)); mean = sum(w pop) / (sum w + 1e-10)
 constexpr int kMppiThreads = 1024;
+constexpr int kMppiTileMax = 256;  // candidates per staged tile of the weighted sum (16 loads per thread); 128 where the weights of a large population leave less LDS
+// dynamic LDS of a launch: the weights [pop] (padded to 16 bytes), the reduction buffer, two tiles of `tile_c` candidates x 64 dimensions
+inline size_t mppi_update_smem(const int pop, const int tile_c) { return ((size_t)((pop + 3) & ~3) + kMppiThreads) * 4 + 2 * (size_t)tile_c * 64 * 4; }
+// candidates per tile (a compile-time fact of the kernel instance: its loads are unconditional and all in flight -- a first version with a
+// run-time count compiled to one `s_waitcnt vmcnt(0)` per load, sixteen dependent round trips per tile: 74 us)
+inline int mppi_update_tile(const int pop, const size_t lds_max) { return mppi_update_smem(pop, kMppiTileMax) + 1024 <= lds_max ? kMppiTileMax : kMppiTileMax / 2; }
+template <int PER>  // tile = 16 PER candidates
 __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int D, float gamma, float* __restrict__ values,
                                                                    const float* __restrict__ population, float* __restrict__ mean) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* w = reinterpret_cast<float*>(smem);                // [pop]
-    float* red = w + pop;                                     // [kMppiThreads]
+    float* red = w + ((pop + 3) & ~3);                        // [kMppiThreads]
+    float* tile = red + kMppiThreads;                         // [2][tile_c][64]
+    constexpr int tile_c = 16 * PER;
     const int tid = threadIdx.x;
     {  // gridDim.y environments
         const int env = blockIdx.y;
@@ -83,30 +140,51 @@ __global__ __launch_bounds__(kMppiThreads) void mppi_update_kernel(int pop, int 
     }
     const float norm = red[0] + 1e-10f;
     // the weighted sum of a dimension is ONE f32 chain over the candidates (the order the reference's sum leaves is not defined; ours is
-    // fixed: c ascending).  Round 6: the chain's loads go out kChunk at a time (the first version waited for every load in turn: 146 us
-    // for pop 2 000 x 300 dimensions), and the dimensions are dealt to the gridDim.x workgroups of the environment, one wave each
-    // (every workgroup repeats the weights above: same inputs, same values).
-    constexpr int kChunk = 32;
-    for (int d = (int)blockIdx.x * 64 + tid; d < D && tid < 64; d += (int)gridDim.x * 64) {
+    // fixed: c ascending), and the dimensions are dealt to the gridDim.x workgroups of the environment 64 at a time (every workgroup
+    // repeats the weights above: same inputs, same values).  The chain is one wave's; what it waits for is the population -- round 6,
+    // first version: the chain's own loads went out 32 at a time, 63 dependent round trips for pop 2 000 (146 -> 102 us).  Now ALL sixteen
+    // waves fetch: a tile of `tile_c` candidates x 64 dimensions per round trip (wave v the rows v, v + 16, ..: 256 coalesced bytes each),
+    // staged in LDS, the next tile in flight while wave 0 walks this one -- the same products added in the same order.
+    const int lane_d = tid & 63, row0 = tid >> 6;
+    for (int d0 = (int)blockIdx.x * 64; d0 < D; d0 += (int)gridDim.x * 64) {
+        const int nd = min(64, D - d0);
+        const float* const col = population + d0 + min(lane_d, nd - 1);
+        float r[PER];
+        auto fetch = [&](const int c0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) r[j] = col[(size_t)min(c0 + row0 + 16 * j, pop - 1) * D];  // (unconditional: a guarded load is a branch and a wait)
+        };
+        auto stash = [&](float* const buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) buf[(row0 + 16 * j) * 64 + lane_d] = r[j];
+        };
+        fetch(0);
+        stash(tile);
+        __syncthreads();
         float acc = 0.f;
-        float xa[kChunk], xb[kChunk];  // two batches: the next one is in flight while this one is summed
-        auto fetch = [&](float (&x)[kChunk], const int c0) __attribute__((always_inline)) {
+        int b = 0;
+        for (int c0 = 0; c0 < pop; c0 += tile_c) {
+            const bool more = c0 + tile_c < pop;  // (uniform)
+            if (more) fetch(c0 + tile_c);
+            if (tid < 64) {
+                const float* const t = tile + (size_t)b * tile_c * 64 + tid;
+                const float* const wc = w + c0;
+                const int n = min(tile_c, pop - c0);
+                int u = 0;
+                for (; u + 8 <= n; u += 8) {  // eight products' operands requested together, added in order
+                    float tv[8], wv[8];
 #pragma unroll
-            for (int u = 0; u < kChunk; ++u) x[u] = population[(size_t)min(c0 + u, pop - 1) * D + d];  // (unconditional: a guarded load is a branch)
-        };
-        auto sum = [&](const float (&x)[kChunk], const int c0) __attribute__((always_inline)) {
+                    for (int k = 0; k < 8; ++k) { tv[k] = t[(u + k) * 64]; wv[k] = wc[u + k]; }
 #pragma unroll
-            for (int u = 0; u < kChunk; ++u)
-                if (c0 + u < pop) acc += x[u] * w[c0 + u];
-        };
-        fetch(xa, 0);
-        for (int c0 = 0; c0 < pop; c0 += 2 * kChunk) {
-            fetch(xb, c0 + kChunk);
-            sum(xa, c0);
-            fetch(xa, c0 + 2 * kChunk);
-            sum(xb, c0 + kChunk);
+                    for (int k = 0; k < 8; ++k) acc += tv[k] * wv[k];
+                }
+                for (; u < n; ++u) acc += t[u * 64] * wc[u];
+            }
+            if (more) stash(tile + (size_t)(b ^ 1) * tile_c * 64);
+            __syncthreads();
+            b ^= 1;
         }
-        mean[d] = acc / norm;
+        if (tid < nd) mean[d0 + tid] = acc / norm;
     }
 }
 

@@ -465,6 +465,59 @@ def _deterministic_objective(engine, obs, act, H, P, members=5, elite=None):
     return _BoundObjective(fn, (np.random.default_rng(3).standard_normal(obs) * 0.1).astype(np.float32))
 
 
+MPPI_SAMPLE_SHAPES = [(2000, 50, 6), (350, 30, 6), (5, 3, 1), (1030, 7, 3), (4, 128, 100)]  # the last: H x A > 12 288, one thread per series
+
+
+@pytest.mark.parametrize("pop,H,A", MPPI_SAMPLE_SHAPES, ids=[f"pop{c[0]}_H{c[1]}_A{c[2]}" for c in MPPI_SAMPLE_SHAPES])
+def test_mppi_sample_shapes(engine, pop, H, A):
+    """trajectory_opt.py:262-295 on its own with injected noise: the beta recurrence on unclipped values, clipping applied to what is stored --
+    bitwise against the same f32 operations in torch (whole candidates staged in LDS, optim.hpp round 6); and the Philox draws of a candidate
+    do not depend on how many candidates share a workgroup."""
+    g = torch.Generator().manual_seed(pop + H)
+    z = torch.randn(pop, H, A, generator=g).clamp(-2, 2)
+    mean, past = torch.randn(H, A, generator=g) * 0.3, torch.randn(A, generator=g) * 0.3
+    lower, upper = -torch.ones(H, A) * 0.8, torch.ones(H, A) * 0.9
+    beta = 0.7
+    out = torch.empty(pop, H, A, device=DEV)
+    engine.mppi_sample(pop, H, A, beta, mean.to(DEV), past.to(DEV), lower.to(DEV), upper.to(DEV), out, z=z.to(DEV).contiguous())
+    b, omb = torch.tensor(beta, dtype=torch.float32), torch.tensor(1.0, dtype=torch.float32) - torch.tensor(beta, dtype=torch.float32)
+    prev, want = past.expand(pop, A).clone(), torch.empty(pop, H, A)
+    for h in range(H):
+        x = b * (mean[h] + z[:, h]) + omb * prev
+        prev = x
+        want[:, h] = torch.maximum(torch.minimum(x, upper[h]), lower[h])
+    assert torch.equal(out.cpu(), want)
+    if pop >= 1030:  # G = pop // 512 candidates per workgroup here, one per workgroup in the smaller call: the same series
+        few = torch.empty(300, H, A, device=DEV)
+        engine.mppi_sample(pop, H, A, beta, mean.to(DEV), past.to(DEV), lower.to(DEV), upper.to(DEV), out, seed=11, stream_id=5)
+        engine.mppi_sample(300, H, A, beta, mean.to(DEV), past.to(DEV), lower.to(DEV), upper.to(DEV), few, seed=11, stream_id=5)
+        assert torch.equal(out[:300].cpu(), few.cpu()) and out.abs().max().item() <= 0.9
+
+
+# (pop, H, A): populations on both sides of a 256-candidate tile and of a 16-row load round, dimension counts below / at / above one wave of 64 and
+# above 32 workgroups' worth (a workgroup then walks several 64-dimension slices), the largest population the ABI accepts
+MPPI_UPDATE_SHAPES = [(2000, 50, 6), (350, 30, 6), (7, 3, 1), (17, 5, 13), (256, 8, 8), (257, 1, 64), (4097, 9, 7), (12000, 4, 3), (300, 64, 40)]
+
+
+@pytest.mark.parametrize("pop,H,A", MPPI_UPDATE_SHAPES, ids=[f"pop{c[0]}_D{c[1] * c[2]}" for c in MPPI_UPDATE_SHAPES])
+def test_mppi_update_shapes(engine, pop, H, A):
+    """trajectory_opt.py:296-309 on its own: NaN -> -1e-10 in place, w = exp(gamma (v - max v)), mean = sum(w x) / (sum w + 1e-10).  The device
+    sum of a dimension is one f32 chain over the candidates, its population staged through LDS tiles (optim.hpp, round 6): against f64."""
+    g = torch.Generator().manual_seed(pop * 31 + H)
+    values = torch.randn(pop, generator=g) * 3
+    values[pop // 2] = float("nan")
+    population = torch.randn(pop, H, A, generator=g)
+    mean = torch.full((H, A), 7.0, device=DEV)
+    vals_dev = values.to(DEV)
+    engine.mppi_update(pop, H, A, 0.9, vals_dev, population.to(DEV).contiguous(), mean)
+    v = values.clone()
+    v[v.isnan()] = -1e-10
+    assert torch.equal(vals_dev.cpu(), v)
+    w = torch.exp(0.9 * (v.double() - v.double().max()))
+    want = (w[:, None, None] * population.double()).sum(0) / (w.sum() + 1e-10)
+    assert torch.allclose(mean.cpu().double(), want, rtol=2e-5, atol=2e-6)
+
+
 def test_fused_mppi_plan_equals_per_iteration_path(engine):
     """hipets_plan_mppi is the MPPIOptimizer.optimize loop (trajectory_opt.py:238-311) enqueued by the library: same
     kernels, same Philox streams => bitwise the same means over consecutive calls (persistent, shifted mean)."""
