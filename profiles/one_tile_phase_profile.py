@@ -81,8 +81,14 @@ def decode(pc, H, unprofiled_ms, profiled_ms):
     return rec
 
 
-for name, obs, act, pop, H, P, rew in [("cfg1_cartpole (BASELINE configs[0]: pop 100 x 5, H 15)", 4, 1, 100, 15, 5, "cartpole"),
-                                       ("cfg2_shard_of_8 (63 candidates x 20, H 30)", 17, 6, 63, 30, 20, "halfcheetah")]:
+CASES = [("cfg1_cartpole (BASELINE configs[0]: pop 100 x 5, H 15)", 4, 1, 100, 15, 5, "cartpole"),
+         ("cfg2_shard_of_8 (63 candidates x 20, H 30)", 17, 6, 63, 30, 20, "halfcheetah")]
+# PHASE_CASES=cfg2: the HEADLINE workload instead (BASELINE configs[1]: pop 500 x 20, H 30 -- the R = 3 instances; a variant built with
+#   python profiles/build_variant.py leanprof3 rollout_r3.hip rollout_r3_fast.hip -DHIPETS_LEAN_PROF=1), no PlaNet
+HEADLINE = os.environ.get("PHASE_CASES") == "cfg2"
+if HEADLINE:
+    CASES = [("cfg2 (BASELINE configs[1]: pop 500 x 20, H 30; 209 three-tile workgroups)", 17, 6, 500, 30, 20, "halfcheetah")]
+for name, obs, act, pop, H, P, rew in CASES:
     om = po.make_synthetic_model(obs, act, ensemble_size=5, hid=200, seed=0, nontrivial_stats=False, reward=rew,
                                  termination="cartpole" if rew == "cartpole" else "no_termination")
     eng.set_model(to_spec(om, obs, act))
@@ -104,6 +110,9 @@ for name, obs, act, pop, H, P, rew in [("cfg1_cartpole (BASELINE configs[0]: pop
             rec[mode].update(decode(pc, H, ums, pms))
     out[name] = rec
 
+if HEADLINE:
+    print(json.dumps(out))
+    sys.exit(0)
 # PlaNet, conf/dynamics_model/planet.yaml sizes, pop 1000 x H 12 (conf/overrides/planet_cheetah_run.yaml): 63 one-tile workgroups
 P_POP, P_H = 1000, 12
 pspec = bench.synthetic_planet_spec(dev)
